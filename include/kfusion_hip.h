@@ -1,0 +1,171 @@
+/*
+ * kfusion_hip.h — C ABI of the gfx950 KinectFusion core (libkfusion_hip_core.so).
+ *
+ * This is the inner boundary of the drop-in: the SLAMBench plugin adapter
+ * (slambench_amd/plugin/kfusion_hip_library.cpp) implements the reference's six plugin entry
+ * points on top of it, and tests / the benchmark call it directly through ctypes.
+ *
+ * Reference interfaces replaced (paths relative to the reference tree):
+ *   - plugin entry points  framework/shared/include/SLAMBenchAPI.h:30-54  (sb_new_slam_configuration,
+ *     sb_init_slam_system, sb_update_frame, sb_process_once, sb_update_outputs, sb_clean_slam_system)
+ *     and their C wrappers framework/shared/src/library_wrapper.cpp:15-44;
+ *   - the kfusion use-case the harness clones at build time (benchmarks/benchmarks.repos:3):
+ *     class Kfusion {preprocessing, tracking, integration, raycasting} and its kernels
+ *     (mm2metersKernel, bilateralFilterKernel, halfSampleRobustImageKernel, depth2vertexKernel,
+ *     vertex2normalKernel, trackKernel, reduceKernel, updatePoseKernel, checkPoseKernel,
+ *     integrateKernel, raycastKernel).  That source is not vendored in the reference tree, so
+ *     those names are cited without line numbers.
+ *
+ * Conventions
+ *   - every function returns KFH_OK (0) or a KFH_ERR_* code; kfh_last_error() gives the text;
+ *   - matrices are 4x4 float, row-major (camera-to-world for poses);
+ *   - images are row-major; vertex / normal maps are float4-strided (x, y, z, unused) in device
+ *     memory; an invalid normal has x == -2;
+ *   - the TSDF volume is short2 per voxel (x: tsdf * 32766, y: weight), index x + y*X + z*X*Y;
+ *   - pointers named d_* are device pointers, h_* host pointers; `stream` is a hipStream_t
+ *     passed as void* (NULL = the default stream).
+ */
+#ifndef KFUSION_HIP_H_
+#define KFUSION_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KFH_OK               0
+#define KFH_ERR_INVALID_ARG  1
+#define KFH_ERR_HIP          2
+#define KFH_ERR_STATE        3
+#define KFH_ERR_NO_DEVICE    4
+
+#define KFH_INVALID_NORMAL  (-2.0f)
+
+/* Plugin parameters (names/defaults: icra2018_results/1080/violons_libkfusion-cpp_living_room_traj0_loop.log:20-31)
+ * plus the sensor description the plugin reads in sb_init_slam_system. */
+typedef struct kfh_config {
+    int32_t input_width, input_height;  /* sensor frame size                                  */
+    int32_t compute_size_ratio;         /* compute-size-ratio: 1, 2, 4 or 8                   */
+    float   fx, fy, cx, cy;             /* intrinsics in INPUT pixels (normalised value * W/H) */
+    float   depth_divisor;              /* raw depth units per metre (1000 for millimetres)   */
+    int32_t vol_res[3];                 /* volume-resolution                                  */
+    float   vol_dim[3];                 /* volume-size, metres                                */
+    float   init_pos[3];                /* volume-direction: initial camera position          */
+    float   mu;                         /* mu                                                 */
+    float   icp_threshold;              /* icp-threshold                                      */
+    int32_t pyramid[3];                 /* pyramid-level1..3, [0] = finest                    */
+    int32_t integration_rate, tracking_rate;
+    int32_t integrate_filtered;         /* 0: fuse raw metres depth, 1: bilateral-filtered    */
+    int32_t slab_z0, slab_z1;           /* z range of the volume held by this device          */
+} kfh_config;
+
+typedef struct kfh_track_data {         /* TrackData of the kfusion use-case */
+    int32_t result;
+    float   error;
+    float   J[6];
+} kfh_track_data;
+
+typedef struct kfh_frame_status {
+    int32_t frame;        /* index of the frame the record belongs to (0-based) */
+    int32_t tracked;      /* checkPose accepted the ICP result                  */
+    int32_t integrated;   /* the TSDF was updated                               */
+    int32_t raycasted;    /* the model maps were re-rendered                    */
+    float   pose[16];     /* pose after the frame                               */
+    float   sums[32];     /* last ICP reduction (layout of reduceKernel)        */
+} kfh_frame_status;
+
+typedef struct kfh_context kfh_context;
+
+/* buffer identifiers for kfh_download / kfh_device_ptr */
+enum kfh_buffer {
+    KFH_BUF_FLOAT_DEPTH = 0,   /* float[h][w]            raw metres                    */
+    KFH_BUF_SCALED_DEPTH = 1,  /* float[h>>l][w>>l]      level l of the filtered pyramid */
+    KFH_BUF_INPUT_VERTEX = 2,  /* float4[h>>l][w>>l]                                    */
+    KFH_BUF_INPUT_NORMAL = 3,  /* float4[h>>l][w>>l]                                    */
+    KFH_BUF_MODEL_VERTEX = 4,  /* float4[h][w]           raycast output                 */
+    KFH_BUF_MODEL_NORMAL = 5,  /* float4[h][w]                                          */
+    KFH_BUF_VOLUME = 6,        /* short2[slab_z1-slab_z0][Y][X]                         */
+    KFH_BUF_RAY_T = 7          /* float[h][w]            hit distance of the last raycast */
+};
+
+const char *kfh_last_error(void);
+int kfh_version(void);
+int kfh_device_count(int *count);
+
+/* ---- lifecycle (sb_init_slam_system / sb_clean_slam_system) ---- */
+int kfh_create(const kfh_config *cfg, kfh_context **out);
+int kfh_destroy(kfh_context *ctx);
+int kfh_reset(kfh_context *ctx);                 /* empty volume, initial pose, frame 0 */
+
+/* ---- frame input (sb_update_frame) ---- */
+int kfh_upload_depth(kfh_context *ctx, const uint16_t *h_depth);      /* async H2D via pinned staging */
+int kfh_set_depth_device(kfh_context *ctx, const uint16_t *d_depth);  /* use a frame already in HBM   */
+
+/* ---- per-frame processing (sb_process_once); all asynchronous on the context's stream ---- */
+int kfh_preprocess(kfh_context *ctx);            /* Kfusion::preprocessing */
+int kfh_track(kfh_context *ctx);                 /* Kfusion::tracking      */
+int kfh_integrate(kfh_context *ctx);             /* Kfusion::integration   */
+int kfh_raycast(kfh_context *ctx);               /* Kfusion::raycasting    */
+int kfh_end_frame(kfh_context *ctx);             /* frame counter ++       */
+int kfh_process_frame(kfh_context *ctx);         /* the five calls above   */
+int kfh_sync(kfh_context *ctx);
+
+/* ---- results (sb_update_outputs) ---- */
+int kfh_get_pose(kfh_context *ctx, float pose[16]);                    /* synchronises */
+int kfh_set_pose(kfh_context *ctx, const float pose[16]);
+int kfh_get_status(kfh_context *ctx, int frame, kfh_frame_status *out); /* synchronises; last 4096 frames kept */
+int kfh_frame_index(kfh_context *ctx, int *frame);
+int kfh_compute_size(kfh_context *ctx, int *w, int *h);
+int kfh_download(kfh_context *ctx, int buffer, int level, void *h_dst, size_t bytes);
+int kfh_device_ptr(kfh_context *ctx, int buffer, int level, void **d_ptr, size_t *bytes);
+int kfh_stream(kfh_context *ctx, void **stream);
+/* event timing of the four phases of the most recent frame processed with timing enabled */
+int kfh_set_timing(kfh_context *ctx, int enabled);
+int kfh_phase_ms(kfh_context *ctx, float ms[4]);
+
+/* ---- z-slab sharding across devices (one context per device) ---- */
+/* March only this context's slab; writes hit distance t (0 = miss), vertex and normal of the nearest
+ * zero crossing inside the slab into the context's model maps (KFH_BUF_RAY_T / MODEL_*). */
+int kfh_raycast_slab(kfh_context *ctx);
+/* Keep, per pixel, the candidate with the smallest positive t among n_parts gathered slab results.
+ * d_t: float[n_parts][h][w], d_vertex / d_normal: float4[n_parts][h][w]; the winners are written into the
+ * context's model maps. */
+int kfh_composite_slabs(kfh_context *ctx, const float *d_t, const void *d_vertex, const void *d_normal,
+                        int n_parts);
+
+/* ---- stateless kernels on caller-owned device memory (used by the parity tests) ---- */
+/* mm2metersKernel (+ bilateralFilterKernel when d_filtered != NULL) */
+int kfh_k_preprocess(float *d_raw, float *d_filtered, int ow, int oh, const uint16_t *d_in, int iw, int ih,
+                     float depth_divisor, void *stream);
+/* bilateralFilterKernel on a float image (radius 2, delta 4.0, e_d 0.1) */
+int kfh_k_bilateral(float *d_out, const float *d_in, int w, int h, void *stream);
+/* halfSampleRobustImageKernel (r = 1) */
+int kfh_k_half_sample(float *d_out, const float *d_in, int iw, int ih, float e_d, void *stream);
+/* depth2vertexKernel + vertex2normalKernel, k = intrinsics of this level */
+int kfh_k_vertex_normal(void *d_vertex4, void *d_normal4, const float *d_depth, int w, int h,
+                        float fx, float fy, float cx, float cy, void *stream);
+/* trackKernel + reduceKernel fused.  d_sums receives 32 floats (reduceKernel layout); d_track (may be NULL)
+ * receives the per-pixel TrackData with row stride `track_stride`. */
+int kfh_k_track_reduce(float *d_sums, kfh_track_data *d_track, int track_stride,
+                       const void *d_in_vertex4, const void *d_in_normal4, int iw, int ih,
+                       const void *d_ref_vertex4, const void *d_ref_normal4, int rw, int rh,
+                       const float Ttrack[16], const float view[16],
+                       float dist_threshold, float normal_threshold, void *stream);
+/* solve + updatePoseKernel on the device: pose <- exp(x) * pose, x (6 doubles) and converged flag out. */
+int kfh_k_update_pose(float *d_pose16, double *d_x6, int *d_converged, const float *d_sums,
+                      float icp_threshold, void *stream);
+/* integrateKernel over z in [z0, z1) of a volume whose storage starts at plane z0 */
+int kfh_k_integrate(void *d_volume, const int32_t res[3], const float dim[3], int z0, int z1,
+                    const float *d_depth, int w, int h, const float invTrack[16], const float K[16],
+                    float mu, float maxweight, void *stream);
+/* raycastKernel */
+int kfh_k_raycast(void *d_vertex4, void *d_normal4, int w, int h, const void *d_volume,
+                  const int32_t res[3], const float dim[3], const float view[16],
+                  float near_plane, float far_plane, float step, float largestep, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KFUSION_HIP_H_ */

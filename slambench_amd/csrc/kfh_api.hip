@@ -1,0 +1,580 @@
+// C ABI of libkfusion_hip_core.so: pipeline context (the Kfusion class of the kfusion use-case re-cast as
+// a single HIP stream of kernels with a device-resident control block) and the stateless kernel entry points.
+#include "kfh_kernels.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+
+using namespace kfh;
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return code;
+}
+
+#define KFH_HIP(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess)                                                                  \
+            return fail(KFH_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_),    \
+                        __FILE__, __LINE__);                                                   \
+    } while (0)
+
+#define KFH_REQUIRE(cond, ...)                                   \
+    do {                                                         \
+        if (!(cond)) return fail(KFH_ERR_INVALID_ARG, __VA_ARGS__); \
+    } while (0)
+
+constexpr float DIST_THRESHOLD = 0.1f;     // Kfusion dist_threshold
+constexpr float NORMAL_THRESHOLD = 0.8f;   // Kfusion normal_threshold
+constexpr float TRACK_THRESHOLD = 0.15f;   // Kfusion track_threshold
+constexpr float MAX_WEIGHT = 100.0f;       // Kfusion maxweight
+constexpr float NEAR_PLANE = 0.4f, FAR_PLANE = 4.0f;
+constexpr float E_DELTA = 0.1f;
+
+}  // namespace
+
+struct kfh_context {
+    kfh_config cfg;
+    int device = 0;
+    int w = 0, h = 0;          // compute size
+    float k[4] = {0, 0, 0, 0}; // intrinsics at compute size
+    int frame = 0;
+    int zs0 = 0, zs1 = 0;      // stored planes (slab + halo)
+    bool sharded = false;
+    hipStream_t stream = nullptr;
+
+    uint16_t *h_depth_pinned = nullptr;
+    uint16_t *d_depth_in = nullptr;        // staging owned by the context
+    const uint16_t *d_depth_cur = nullptr; // frame to process (staging or caller-owned)
+    float *d_float_depth = nullptr;
+    float *d_scaled[3] = {nullptr, nullptr, nullptr};
+    float4 *d_in_vertex[3] = {nullptr, nullptr, nullptr};
+    float4 *d_in_normal[3] = {nullptr, nullptr, nullptr};
+    float4 *d_vertex = nullptr, *d_normal = nullptr;
+    float *d_ray_t = nullptr;
+    short2 *d_volume = nullptr;
+    size_t volume_voxels = 0;
+    float *d_partials = nullptr;
+    Ctrl *d_ctrl = nullptr;
+    kfh_frame_status *d_status = nullptr;
+
+    bool timing = false;
+    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    bool ev_valid = false;
+};
+
+namespace {
+
+int validate_config(const kfh_config *c) {
+    KFH_REQUIRE(c != nullptr, "config is NULL");
+    KFH_REQUIRE(c->input_width > 0 && c->input_height > 0, "input size must be positive");
+    const int r = c->compute_size_ratio;
+    KFH_REQUIRE(r == 1 || r == 2 || r == 4 || r == 8, "compute_size_ratio must be 1, 2, 4 or 8 (got %d)", r);
+    KFH_REQUIRE(c->input_width % (4 * r) == 0 && c->input_height % (4 * r) == 0,
+                "input size %dx%d must be divisible by 4*compute_size_ratio", c->input_width, c->input_height);
+    KFH_REQUIRE(c->fx != 0.f && c->fy != 0.f, "focal lengths must be non-zero");
+    KFH_REQUIRE(c->depth_divisor > 0.f, "depth_divisor must be positive");
+    for (int i = 0; i < 3; ++i) {
+        KFH_REQUIRE(c->vol_res[i] > 0 && c->vol_res[i] <= 4096, "vol_res[%d]=%d out of range", i, c->vol_res[i]);
+        KFH_REQUIRE(c->vol_dim[i] > 0.f, "vol_dim[%d] must be positive", i);
+        KFH_REQUIRE(c->pyramid[i] >= 0 && c->pyramid[i] <= 64, "pyramid[%d]=%d out of range", i, c->pyramid[i]);
+    }
+    KFH_REQUIRE(c->mu > 0.f, "mu must be positive");
+    KFH_REQUIRE(c->integration_rate >= 1 && c->tracking_rate >= 1, "rates must be >= 1");
+    KFH_REQUIRE(c->slab_z0 >= 0 && c->slab_z0 < c->slab_z1 && c->slab_z1 <= c->vol_res[2],
+                "slab [%d,%d) must lie inside [0,%d)", c->slab_z0, c->slab_z1, c->vol_res[2]);
+    return KFH_OK;
+}
+
+template <typename T>
+hipError_t dev_alloc(T **p, size_t count) {
+    return hipMalloc(reinterpret_cast<void **>(p), count * sizeof(T));
+}
+
+void free_all(kfh_context *c) {
+    if (c->h_depth_pinned) (void)hipHostFree(c->h_depth_pinned);
+    void *bufs[] = {c->d_depth_in, c->d_float_depth, c->d_scaled[0], c->d_scaled[1], c->d_scaled[2],
+                    c->d_in_vertex[0], c->d_in_vertex[1], c->d_in_vertex[2], c->d_in_normal[0],
+                    c->d_in_normal[1], c->d_in_normal[2], c->d_vertex, c->d_normal, c->d_ray_t, c->d_volume,
+                    c->d_partials, c->d_ctrl, c->d_status};
+    for (void *b : bufs)
+        if (b) (void)hipFree(b);
+    for (auto &e : c->ev)
+        if (e) (void)hipEventDestroy(e);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+}
+
+int init_state(kfh_context *c) {
+    const size_t npix = (size_t)c->w * c->h;
+    KFH_HIP(launch_fill_volume(c->d_volume, c->volume_voxels, c->stream));
+    KFH_HIP(hipMemsetAsync(c->d_vertex, 0, npix * sizeof(float4), c->stream));
+    KFH_HIP(hipMemsetAsync(c->d_normal, 0, npix * sizeof(float4), c->stream));
+    KFH_HIP(hipMemsetAsync(c->d_ray_t, 0, npix * sizeof(float), c->stream));
+    KFH_HIP(hipMemsetAsync(c->d_status, 0, sizeof(kfh_frame_status) * KFH_STATUS_RING, c->stream));
+    Ctrl init;
+    std::memset(&init, 0, sizeof(init));
+    const float p[16] = {1, 0, 0, c->cfg.init_pos[0], 0, 1, 0, c->cfg.init_pos[1],
+                         0, 0, 1, c->cfg.init_pos[2], 0, 0, 0, 1};
+    std::memcpy(init.pose.m, p, sizeof(p));
+    KFH_HIP(hipMemcpyAsync(c->d_ctrl, &init, sizeof(Ctrl), hipMemcpyHostToDevice, c->stream));
+    KFH_HIP(hipStreamSynchronize(c->stream));   // `init` lives on this stack frame
+    KFH_HIP(launch_pose_derive(c->d_ctrl, c->k, 1, c->stream));
+    c->frame = 0;
+    c->d_depth_cur = c->d_depth_in;
+    c->ev_valid = false;
+    return KFH_OK;
+}
+
+SolveArgs solve_args(const kfh_context *c) {
+    SolveArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.ctrl = c->d_ctrl;
+    a.partials = c->d_partials;
+    a.w = c->w;
+    a.h = c->h;
+    a.icp_threshold = c->cfg.icp_threshold;
+    a.track_threshold = TRACK_THRESHOLD;
+    for (int i = 0; i < 4; ++i) a.k[i] = c->k[i];
+    a.will_raycast = c->frame > 2 ? 1 : 0;
+    a.frame = c->frame;
+    a.integration_rate = c->cfg.integration_rate;
+    a.status_ring = c->d_status;
+    return a;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *kfh_last_error(void) { return g_last_error.c_str(); }
+int kfh_version(void) { return 100; }
+
+int kfh_device_count(int *count) {
+    KFH_REQUIRE(count != nullptr, "count is NULL");
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) n = 0;
+    *count = n;
+    return KFH_OK;
+}
+
+int kfh_create(const kfh_config *cfg, kfh_context **out) {
+    KFH_REQUIRE(out != nullptr, "out is NULL");
+    *out = nullptr;
+    if (int rc = validate_config(cfg)) return rc;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        return fail(KFH_ERR_NO_DEVICE, "no HIP device is visible to this process");
+    kfh_context *c = new (std::nothrow) kfh_context();
+    if (!c) return fail(KFH_ERR_STATE, "out of host memory");
+    c->cfg = *cfg;
+    const int r = cfg->compute_size_ratio;
+    c->w = cfg->input_width / r;
+    c->h = cfg->input_height / r;
+    c->k[0] = cfg->fx / (float)r; c->k[1] = cfg->fy / (float)r;
+    c->k[2] = cfg->cx / (float)r; c->k[3] = cfg->cy / (float)r;
+    c->sharded = !(cfg->slab_z0 == 0 && cfg->slab_z1 == cfg->vol_res[2]);
+    c->zs0 = c->sharded ? (cfg->slab_z0 - 2 > 0 ? cfg->slab_z0 - 2 : 0) : 0;
+    c->zs1 = c->sharded ? (cfg->slab_z1 + 2 < cfg->vol_res[2] ? cfg->slab_z1 + 2 : cfg->vol_res[2]) : cfg->vol_res[2];
+    c->volume_voxels = (size_t)cfg->vol_res[0] * cfg->vol_res[1] * (size_t)(c->zs1 - c->zs0);
+
+    const size_t npix = (size_t)c->w * c->h;
+    const size_t nin = (size_t)cfg->input_width * cfg->input_height;
+    hipError_t e = hipGetDevice(&c->device);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&c->h_depth_pinned), nin * sizeof(uint16_t), hipHostMallocDefault);
+    if (e == hipSuccess) e = dev_alloc(&c->d_depth_in, nin);
+    if (e == hipSuccess) e = dev_alloc(&c->d_float_depth, npix);
+    for (int l = 0; l < 3 && e == hipSuccess; ++l) {
+        const size_t nl = (size_t)(c->w >> l) * (c->h >> l);
+        e = dev_alloc(&c->d_scaled[l], nl);
+        if (e == hipSuccess) e = dev_alloc(&c->d_in_vertex[l], nl);
+        if (e == hipSuccess) e = dev_alloc(&c->d_in_normal[l], nl);
+    }
+    if (e == hipSuccess) e = dev_alloc(&c->d_vertex, npix);
+    if (e == hipSuccess) e = dev_alloc(&c->d_normal, npix);
+    if (e == hipSuccess) e = dev_alloc(&c->d_ray_t, npix);
+    if (e == hipSuccess) e = dev_alloc(&c->d_volume, c->volume_voxels);
+    if (e == hipSuccess) e = dev_alloc(&c->d_partials, (size_t)track_blocks(c->w, c->h) * 32);
+    if (e == hipSuccess) e = dev_alloc(&c->d_ctrl, 1);
+    if (e == hipSuccess) e = dev_alloc(&c->d_status, KFH_STATUS_RING);
+    for (int i = 0; i < 5 && e == hipSuccess; ++i) e = hipEventCreate(&c->ev[i]);
+    if (e != hipSuccess) {
+        free_all(c);
+        delete c;
+        return fail(KFH_ERR_HIP, "allocation failed: %s", hipGetErrorString(e));
+    }
+    if (int rc = init_state(c)) {
+        free_all(c);
+        delete c;
+        return rc;
+    }
+    *out = c;
+    return KFH_OK;
+}
+
+int kfh_destroy(kfh_context *c) {
+    if (!c) return KFH_OK;
+    (void)hipStreamSynchronize(c->stream);
+    free_all(c);
+    delete c;
+    return KFH_OK;
+}
+
+int kfh_reset(kfh_context *c) {
+    KFH_REQUIRE(c != nullptr, "context is NULL");
+    return init_state(c);
+}
+
+int kfh_upload_depth(kfh_context *c, const uint16_t *h_depth) {
+    KFH_REQUIRE(c != nullptr && h_depth != nullptr, "NULL argument");
+    const size_t bytes = (size_t)c->cfg.input_width * c->cfg.input_height * sizeof(uint16_t);
+    // the pinned buffer may still feed the previous frame's copy
+    KFH_HIP(hipStreamSynchronize(c->stream));
+    std::memcpy(c->h_depth_pinned, h_depth, bytes);
+    KFH_HIP(hipMemcpyAsync(c->d_depth_in, c->h_depth_pinned, bytes, hipMemcpyHostToDevice, c->stream));
+    c->d_depth_cur = c->d_depth_in;
+    return KFH_OK;
+}
+
+int kfh_set_depth_device(kfh_context *c, const uint16_t *d_depth) {
+    KFH_REQUIRE(c != nullptr && d_depth != nullptr, "NULL argument");
+    c->d_depth_cur = d_depth;
+    return KFH_OK;
+}
+
+int kfh_preprocess(kfh_context *c) {
+    KFH_REQUIRE(c != nullptr, "context is NULL");
+    if (c->timing) KFH_HIP(hipEventRecord(c->ev[0], c->stream));
+    KFH_HIP(launch_preprocess(c->d_float_depth, c->d_scaled[0], c->w, c->h, c->d_depth_cur, true,
+                              c->cfg.input_width, c->cfg.compute_size_ratio, c->cfg.depth_divisor, c->stream));
+    if (c->timing) KFH_HIP(hipEventRecord(c->ev[1], c->stream));
+    return KFH_OK;
+}
+
+int kfh_track(kfh_context *c) {
+    KFH_REQUIRE(c != nullptr, "context is NULL");
+    SolveArgs a = solve_args(c);
+    int final_level = -1;
+    for (int l = 0; l < 3; ++l)
+        if (c->cfg.pyramid[l] > 0) { final_level = l; break; }
+    if (c->frame % c->cfg.tracking_rate != 0 || final_level < 0) {
+        KFH_HIP(launch_track_skip(a, c->stream));
+    } else {
+        for (int l = 1; l < 3; ++l)
+            KFH_HIP(launch_half_sample(c->d_scaled[l], c->d_scaled[l - 1], c->w >> (l - 1), c->h >> (l - 1),
+                                       E_DELTA * 3, c->stream));
+        for (int l = 0; l < 3; ++l) {
+            const float s = (float)(1 << l);
+            KFH_HIP(launch_vertex_normal(c->d_in_vertex[l], c->d_in_normal[l], c->d_scaled[l], c->w >> l,
+                                         c->h >> l, c->k[0] / s, c->k[1] / s, c->k[2] / s, c->k[3] / s, c->stream));
+        }
+        for (int level = 2; level >= 0; --level) {
+            const int lw = c->w >> level, lh = c->h >> level;
+            const int nb = track_blocks(lw, lh);
+            for (int i = 0; i < c->cfg.pyramid[level]; ++i) {
+                KFH_HIP(launch_track_reduce(c->d_partials, nullptr, 0, c->d_in_vertex[level], c->d_in_normal[level],
+                                            lw, lh, c->d_vertex, c->d_normal, c->w, c->h, &c->d_ctrl->pose,
+                                            &c->d_ctrl->project_ref, DIST_THRESHOLD, NORMAL_THRESHOLD,
+                                            &c->d_ctrl->level_done[level], c->frame + 1, c->stream));
+                a.nblocks = nb;
+                a.level = level;
+                a.last_iter_of_level = (i == c->cfg.pyramid[level] - 1) ? 1 : 0;
+                a.final_level = (level == final_level) ? 1 : 0;
+                KFH_HIP(launch_icp_solve(a, c->stream));
+            }
+        }
+    }
+    if (c->timing) KFH_HIP(hipEventRecord(c->ev[2], c->stream));
+    return KFH_OK;
+}
+
+int kfh_integrate(kfh_context *c) {
+    KFH_REQUIRE(c != nullptr, "context is NULL");
+    if ((c->frame % c->cfg.integration_rate) == 0 || c->frame <= 3) {
+        const float *src = c->cfg.integrate_filtered ? c->d_scaled[0] : c->d_float_depth;
+        // planes [zs0, zs1) are stored; the kernel replays the z < zs0 steps of each column arithmetically
+        KFH_HIP(launch_integrate(c->d_volume, c->cfg.vol_res, c->cfg.vol_dim, c->zs0, c->zs1, src, c->w, c->h,
+                                 &c->d_ctrl->inv_pose, camera_matrix(c->k[0], c->k[1], c->k[2], c->k[3]),
+                                 c->cfg.mu, MAX_WEIGHT, &c->d_ctrl->integrate_gate, c->stream));
+    }
+    if (c->timing) KFH_HIP(hipEventRecord(c->ev[3], c->stream));
+    return KFH_OK;
+}
+
+static float raycast_step(const kfh_config &cfg) {
+    const float mind = fminf(cfg.vol_dim[0], fminf(cfg.vol_dim[1], cfg.vol_dim[2]));
+    int maxr = cfg.vol_res[0];
+    if (cfg.vol_res[1] > maxr) maxr = cfg.vol_res[1];
+    if (cfg.vol_res[2] > maxr) maxr = cfg.vol_res[2];
+    return mind / (float)maxr;
+}
+
+int kfh_raycast(kfh_context *c) {
+    KFH_REQUIRE(c != nullptr, "context is NULL");
+    if (c->frame > 2 && !c->sharded) {
+        KFH_HIP(launch_raycast(c->d_vertex, c->d_normal, c->d_ray_t, c->w, c->h, c->d_volume, c->cfg.vol_res,
+                               c->cfg.vol_dim, 0, c->cfg.vol_res[2], &c->d_ctrl->view, NEAR_PLANE, FAR_PLANE,
+                               raycast_step(c->cfg), 0.75f * c->cfg.mu, c->stream));
+    }
+    if (c->timing) {
+        KFH_HIP(hipEventRecord(c->ev[4], c->stream));
+        c->ev_valid = true;
+    }
+    return KFH_OK;
+}
+
+int kfh_raycast_slab(kfh_context *c) {
+    KFH_REQUIRE(c != nullptr, "context is NULL");
+    if (c->frame > 2) {
+        KFH_HIP(launch_raycast(c->d_vertex, c->d_normal, c->d_ray_t, c->w, c->h, c->d_volume, c->cfg.vol_res,
+                               c->cfg.vol_dim, c->cfg.slab_z0, c->cfg.slab_z1, &c->d_ctrl->view, NEAR_PLANE,
+                               FAR_PLANE, raycast_step(c->cfg), 0.75f * c->cfg.mu, c->stream));
+    }
+    return KFH_OK;
+}
+
+int kfh_composite_slabs(kfh_context *c, const float *d_t, const void *d_vertex, const void *d_normal, int n_parts) {
+    KFH_REQUIRE(c != nullptr && d_t && d_vertex && d_normal, "NULL argument");
+    KFH_REQUIRE(n_parts >= 1 && n_parts <= 64, "n_parts=%d out of range", n_parts);
+    if (c->frame > 2) {
+        KFH_HIP(launch_composite(c->d_vertex, c->d_normal, c->d_ray_t, d_t, static_cast<const float4 *>(d_vertex),
+                                 static_cast<const float4 *>(d_normal), n_parts, c->w * c->h, c->stream));
+    }
+    return KFH_OK;
+}
+
+int kfh_end_frame(kfh_context *c) {
+    KFH_REQUIRE(c != nullptr, "context is NULL");
+    c->frame++;
+    return KFH_OK;
+}
+
+int kfh_process_frame(kfh_context *c) {
+    if (int rc = kfh_preprocess(c)) return rc;
+    if (int rc = kfh_track(c)) return rc;
+    if (int rc = kfh_integrate(c)) return rc;
+    if (int rc = kfh_raycast(c)) return rc;
+    return kfh_end_frame(c);
+}
+
+int kfh_sync(kfh_context *c) {
+    KFH_REQUIRE(c != nullptr, "context is NULL");
+    KFH_HIP(hipStreamSynchronize(c->stream));
+    return KFH_OK;
+}
+
+int kfh_get_pose(kfh_context *c, float pose[16]) {
+    KFH_REQUIRE(c != nullptr && pose != nullptr, "NULL argument");
+    KFH_HIP(hipMemcpyAsync(pose, &c->d_ctrl->pose, sizeof(Mat4), hipMemcpyDeviceToHost, c->stream));
+    KFH_HIP(hipStreamSynchronize(c->stream));
+    return KFH_OK;
+}
+
+int kfh_set_pose(kfh_context *c, const float pose[16]) {
+    KFH_REQUIRE(c != nullptr && pose != nullptr, "NULL argument");
+    KFH_HIP(hipMemcpyAsync(&c->d_ctrl->pose, pose, sizeof(Mat4), hipMemcpyHostToDevice, c->stream));
+    KFH_HIP(hipStreamSynchronize(c->stream));
+    KFH_HIP(launch_pose_derive(c->d_ctrl, c->k, 0, c->stream));
+    return KFH_OK;
+}
+
+int kfh_get_status(kfh_context *c, int frame, kfh_frame_status *out) {
+    KFH_REQUIRE(c != nullptr && out != nullptr, "NULL argument");
+    KFH_REQUIRE(frame >= 0 && frame < c->frame && frame >= c->frame - KFH_STATUS_RING,
+                "frame %d is not in the retained window (%d frames processed)", frame, c->frame);
+    KFH_HIP(hipMemcpyAsync(out, c->d_status + (frame % KFH_STATUS_RING), sizeof(kfh_frame_status),
+                           hipMemcpyDeviceToHost, c->stream));
+    KFH_HIP(hipStreamSynchronize(c->stream));
+    return KFH_OK;
+}
+
+int kfh_frame_index(kfh_context *c, int *frame) {
+    KFH_REQUIRE(c != nullptr && frame != nullptr, "NULL argument");
+    *frame = c->frame;
+    return KFH_OK;
+}
+
+int kfh_compute_size(kfh_context *c, int *w, int *h) {
+    KFH_REQUIRE(c != nullptr && w != nullptr && h != nullptr, "NULL argument");
+    *w = c->w;
+    *h = c->h;
+    return KFH_OK;
+}
+
+int kfh_device_ptr(kfh_context *c, int buffer, int level, void **d_ptr, size_t *bytes) {
+    KFH_REQUIRE(c != nullptr && d_ptr != nullptr && bytes != nullptr, "NULL argument");
+    KFH_REQUIRE(level >= 0 && level < 3, "level %d out of range", level);
+    const size_t npix = (size_t)c->w * c->h;
+    const size_t nl = (size_t)(c->w >> level) * (c->h >> level);
+    switch (buffer) {
+        case KFH_BUF_FLOAT_DEPTH: *d_ptr = c->d_float_depth; *bytes = npix * sizeof(float); break;
+        case KFH_BUF_SCALED_DEPTH: *d_ptr = c->d_scaled[level]; *bytes = nl * sizeof(float); break;
+        case KFH_BUF_INPUT_VERTEX: *d_ptr = c->d_in_vertex[level]; *bytes = nl * sizeof(float4); break;
+        case KFH_BUF_INPUT_NORMAL: *d_ptr = c->d_in_normal[level]; *bytes = nl * sizeof(float4); break;
+        case KFH_BUF_MODEL_VERTEX: *d_ptr = c->d_vertex; *bytes = npix * sizeof(float4); break;
+        case KFH_BUF_MODEL_NORMAL: *d_ptr = c->d_normal; *bytes = npix * sizeof(float4); break;
+        case KFH_BUF_VOLUME: *d_ptr = c->d_volume; *bytes = c->volume_voxels * sizeof(short2); break;
+        case KFH_BUF_RAY_T: *d_ptr = c->d_ray_t; *bytes = npix * sizeof(float); break;
+        default: return fail(KFH_ERR_INVALID_ARG, "unknown buffer id %d", buffer);
+    }
+    return KFH_OK;
+}
+
+int kfh_download(kfh_context *c, int buffer, int level, void *h_dst, size_t bytes) {
+    KFH_REQUIRE(h_dst != nullptr, "destination is NULL");
+    void *src = nullptr;
+    size_t have = 0;
+    if (int rc = kfh_device_ptr(c, buffer, level, &src, &have)) return rc;
+    KFH_REQUIRE(bytes <= have, "requested %zu bytes, buffer holds %zu", bytes, have);
+    KFH_HIP(hipMemcpyAsync(h_dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+    KFH_HIP(hipStreamSynchronize(c->stream));
+    return KFH_OK;
+}
+
+int kfh_stream(kfh_context *c, void **stream) {
+    KFH_REQUIRE(c != nullptr && stream != nullptr, "NULL argument");
+    *stream = c->stream;
+    return KFH_OK;
+}
+
+int kfh_set_timing(kfh_context *c, int enabled) {
+    KFH_REQUIRE(c != nullptr, "context is NULL");
+    c->timing = enabled != 0;
+    c->ev_valid = false;
+    return KFH_OK;
+}
+
+int kfh_phase_ms(kfh_context *c, float ms[4]) {
+    KFH_REQUIRE(c != nullptr && ms != nullptr, "NULL argument");
+    if (!c->ev_valid) return fail(KFH_ERR_STATE, "no frame has been processed with timing enabled");
+    KFH_HIP(hipEventSynchronize(c->ev[4]));
+    for (int i = 0; i < 4; ++i) KFH_HIP(hipEventElapsedTime(&ms[i], c->ev[i], c->ev[i + 1]));
+    return KFH_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// stateless kernels
+// ------------------------------------------------------------------------------------------------------
+int kfh_k_preprocess(float *d_raw, float *d_filtered, int ow, int oh, const uint16_t *d_in, int iw, int ih,
+                     float depth_divisor, void *stream) {
+    KFH_REQUIRE(d_in != nullptr && (d_raw || d_filtered), "NULL argument");
+    KFH_REQUIRE(ow > 0 && oh > 0 && iw >= ow && ih >= oh, "bad sizes");
+    KFH_REQUIRE(iw % ow == 0 && ih % oh == 0 && iw / ow == ih / oh, "input size must be an integer multiple of the output size");
+    KFH_REQUIRE(depth_divisor > 0.f, "depth_divisor must be positive");
+    KFH_HIP(launch_preprocess(d_raw, d_filtered, ow, oh, d_in, true, iw, iw / ow, depth_divisor,
+                              static_cast<hipStream_t>(stream)));
+    return KFH_OK;
+}
+
+int kfh_k_bilateral(float *d_out, const float *d_in, int w, int h, void *stream) {
+    KFH_REQUIRE(d_out && d_in && w > 0 && h > 0, "bad argument");
+    KFH_HIP(launch_preprocess(nullptr, d_out, w, h, d_in, false, w, 1, 1.0f, static_cast<hipStream_t>(stream)));
+    return KFH_OK;
+}
+
+int kfh_k_half_sample(float *d_out, const float *d_in, int iw, int ih, float e_d, void *stream) {
+    KFH_REQUIRE(d_out && d_in && iw >= 2 && ih >= 2 && iw % 2 == 0 && ih % 2 == 0, "bad argument");
+    KFH_HIP(launch_half_sample(d_out, d_in, iw, ih, e_d, static_cast<hipStream_t>(stream)));
+    return KFH_OK;
+}
+
+int kfh_k_vertex_normal(void *d_vertex4, void *d_normal4, const float *d_depth, int w, int h, float fx, float fy,
+                        float cx, float cy, void *stream) {
+    KFH_REQUIRE(d_vertex4 && d_normal4 && d_depth && w > 0 && h > 0, "bad argument");
+    KFH_HIP(launch_vertex_normal(static_cast<float4 *>(d_vertex4), static_cast<float4 *>(d_normal4), d_depth, w, h,
+                                 fx, fy, cx, cy, static_cast<hipStream_t>(stream)));
+    return KFH_OK;
+}
+
+int kfh_k_track_reduce(float *d_sums, kfh_track_data *d_track, int track_stride, const void *d_in_vertex4,
+                       const void *d_in_normal4, int iw, int ih, const void *d_ref_vertex4,
+                       const void *d_ref_normal4, int rw, int rh, const float Ttrack[16], const float view[16],
+                       float dist_threshold, float normal_threshold, void *stream) {
+    KFH_REQUIRE(d_sums && d_in_vertex4 && d_in_normal4 && d_ref_vertex4 && d_ref_normal4 && Ttrack && view,
+                "NULL argument");
+    KFH_REQUIRE(iw > 0 && ih > 0 && rw > 0 && rh > 0, "bad sizes");
+    KFH_REQUIRE(!d_track || track_stride >= iw, "track_stride must be >= iw");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int nb = track_blocks(iw, ih);
+    float *scratch = nullptr;   // [2 matrices | partials]
+    KFH_HIP(hipMalloc(reinterpret_cast<void **>(&scratch), (32 + (size_t)nb * 32) * sizeof(float)));
+    hipError_t e = hipMemcpyAsync(scratch, Ttrack, 16 * sizeof(float), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(scratch + 16, view, 16 * sizeof(float), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess)
+        e = launch_track_reduce(scratch + 32, d_track, track_stride, static_cast<const float4 *>(d_in_vertex4),
+                                static_cast<const float4 *>(d_in_normal4), iw, ih,
+                                static_cast<const float4 *>(d_ref_vertex4), static_cast<const float4 *>(d_ref_normal4),
+                                rw, rh, reinterpret_cast<const Mat4 *>(scratch), reinterpret_cast<const Mat4 *>(scratch + 16),
+                                dist_threshold, normal_threshold, nullptr, 0, s);
+    if (e == hipSuccess) e = launch_sum_partials(d_sums, scratch + 32, nb, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    (void)hipFree(scratch);
+    KFH_HIP(e);
+    return KFH_OK;
+}
+
+int kfh_k_update_pose(float *d_pose16, double *d_x6, int *d_converged, const float *d_sums, float icp_threshold,
+                      void *stream) {
+    KFH_REQUIRE(d_pose16 && d_x6 && d_converged && d_sums, "NULL argument");
+    KFH_HIP(launch_update_pose(d_pose16, d_x6, d_converged, d_sums, icp_threshold, static_cast<hipStream_t>(stream)));
+    return KFH_OK;
+}
+
+int kfh_k_integrate(void *d_volume, const int32_t res[3], const float dim[3], int z0, int z1, const float *d_depth,
+                    int w, int h, const float invTrack[16], const float K[16], float mu, float maxweight,
+                    void *stream) {
+    KFH_REQUIRE(d_volume && res && dim && d_depth && invTrack && K, "NULL argument");
+    KFH_REQUIRE(res[0] > 0 && res[1] > 0 && res[2] > 0 && 0 <= z0 && z0 < z1 && z1 <= res[2], "bad volume range");
+    KFH_REQUIRE(w > 0 && h > 0 && mu > 0.f, "bad argument");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    Mat4 *d_inv = nullptr;
+    KFH_HIP(hipMalloc(reinterpret_cast<void **>(&d_inv), sizeof(Mat4)));
+    Mat4 Km;
+    std::memcpy(Km.m, K, sizeof(Km.m));
+    hipError_t e = hipMemcpyAsync(d_inv, invTrack, sizeof(Mat4), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess)
+        e = launch_integrate(static_cast<short2 *>(d_volume), res, dim, z0, z1, d_depth, w, h, d_inv, Km, mu,
+                             maxweight, nullptr, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    (void)hipFree(d_inv);
+    KFH_HIP(e);
+    return KFH_OK;
+}
+
+int kfh_k_raycast(void *d_vertex4, void *d_normal4, int w, int h, const void *d_volume, const int32_t res[3],
+                  const float dim[3], const float view[16], float near_plane, float far_plane, float step,
+                  float largestep, void *stream) {
+    KFH_REQUIRE(d_vertex4 && d_normal4 && d_volume && res && dim && view, "NULL argument");
+    KFH_REQUIRE(w > 0 && h > 0 && res[0] > 0 && res[1] > 0 && res[2] > 0, "bad sizes");
+    KFH_REQUIRE(step > 0.f && largestep > 0.f, "steps must be positive");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    Mat4 *d_view = nullptr;
+    KFH_HIP(hipMalloc(reinterpret_cast<void **>(&d_view), sizeof(Mat4)));
+    hipError_t e = hipMemcpyAsync(d_view, view, sizeof(Mat4), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess)
+        e = launch_raycast(static_cast<float4 *>(d_vertex4), static_cast<float4 *>(d_normal4), nullptr, w, h,
+                           static_cast<const short2 *>(d_volume), res, dim, 0, res[2], d_view, near_plane,
+                           far_plane, step, largestep, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    (void)hipFree(d_view);
+    KFH_HIP(e);
+    return KFH_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,162 @@
+"""Host-side mirror of the kfusion use-case's `Kfusion` class on top of the C ABI.
+
+Method names follow the use-case (preprocessing / tracking / integration / raycasting are the four
+phases the plugin brackets in sb_process_once; the reference's log header lists them as
+Duration_Preprocessing .. Duration_Raycasting,
+icra2018_results/1080/violons_libkfusion-cpp_living_room_traj0_loop.log:36).  All work is queued on
+the context's HIP stream; only the accessors synchronise.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import native
+from .config import KFusionConfig
+
+
+def _device_pointer(obj):
+    """Device address of a caller-owned buffer: an int, or anything with .data_ptr() (torch tensors)."""
+    if isinstance(obj, int):
+        return obj
+    if hasattr(obj, "data_ptr"):
+        return int(obj.data_ptr())
+    raise TypeError("expected a device pointer (int) or an object with data_ptr()")
+
+
+class KFusion:
+    def __init__(self, cfg: KFusionConfig):
+        self.cfg = cfg
+        self._L = native.lib()
+        self._ctx = C.c_void_p()
+        ccfg = cfg.to_c()
+        native.check(self._L.kfh_create(C.byref(ccfg), C.byref(self._ctx)))
+        self.width, self.height = cfg.compute_size
+
+    # ------------------------------------------------------------------ lifecycle
+    def close(self):
+        if getattr(self, "_ctx", None) and self._ctx.value:
+            self._L.kfh_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def reset(self):
+        native.check(self._L.kfh_reset(self._ctx))
+
+    # ------------------------------------------------------------------ frame input
+    def set_depth(self, depth):
+        """Host uint16 array [H, W] (copied through pinned staging) or a device buffer already in HBM."""
+        if isinstance(depth, np.ndarray):
+            w, h = self.cfg.input_size
+            if depth.dtype != np.uint16 or depth.shape != (h, w):
+                raise ValueError("depth must be uint16 [%d, %d]" % (h, w))
+            d = np.ascontiguousarray(depth)
+            native.check(self._L.kfh_upload_depth(self._ctx, d.ctypes.data_as(C.c_void_p)))
+        else:
+            native.check(self._L.kfh_set_depth_device(self._ctx, C.c_void_p(_device_pointer(depth))))
+
+    # ------------------------------------------------------------------ phases
+    def preprocessing(self):
+        native.check(self._L.kfh_preprocess(self._ctx))
+
+    def tracking(self):
+        native.check(self._L.kfh_track(self._ctx))
+
+    def integration(self):
+        native.check(self._L.kfh_integrate(self._ctx))
+
+    def raycasting(self):
+        native.check(self._L.kfh_raycast(self._ctx))
+
+    def end_frame(self):
+        native.check(self._L.kfh_end_frame(self._ctx))
+
+    def process_frame(self, depth=None):
+        """One sb_process_once: preprocessing -> tracking -> integration -> raycasting."""
+        if depth is not None:
+            self.set_depth(depth)
+        native.check(self._L.kfh_process_frame(self._ctx))
+
+    def sync(self):
+        native.check(self._L.kfh_sync(self._ctx))
+
+    # ------------------------------------------------------------------ results
+    @property
+    def frame(self):
+        f = C.c_int()
+        native.check(self._L.kfh_frame_index(self._ctx, C.byref(f)))
+        return f.value
+
+    @property
+    def pose(self):
+        out = np.empty(16, np.float32)
+        native.check(self._L.kfh_get_pose(self._ctx, out.ctypes.data_as(C.c_void_p)))
+        return out.reshape(4, 4)
+
+    def set_pose(self, pose):
+        p = np.ascontiguousarray(pose, dtype=np.float32).reshape(16)
+        native.check(self._L.kfh_set_pose(self._ctx, p.ctypes.data_as(C.c_void_p)))
+
+    def status(self, frame):
+        st = native.FrameStatus()
+        native.check(self._L.kfh_get_status(self._ctx, int(frame), C.byref(st)))
+        return {
+            "frame": st.frame, "tracked": bool(st.tracked), "integrated": bool(st.integrated),
+            "raycasted": bool(st.raycasted),
+            "pose": np.array(st.pose, np.float32).reshape(4, 4),
+            "sums": np.array(st.sums, np.float32),
+        }
+
+    def trajectory(self, first=0, count=None):
+        n = self.frame
+        if count is None:
+            count = n - first
+        return np.stack([self.status(f)["pose"] for f in range(first, first + count)]) if count > 0 else \
+            np.zeros((0, 4, 4), np.float32)
+
+    def device_ptr(self, buffer, level=0):
+        p, n = C.c_void_p(), C.c_size_t()
+        native.check(self._L.kfh_device_ptr(self._ctx, buffer, level, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def stream(self):
+        s = C.c_void_p()
+        native.check(self._L.kfh_stream(self._ctx, C.byref(s)))
+        return s.value
+
+    def download(self, buffer, level=0):
+        """Copy one of the context's buffers to a numpy array (synchronises)."""
+        _, nbytes = self.device_ptr(buffer, level)
+        w, h = self.width >> level, self.height >> level
+        if buffer in (native.BUF_FLOAT_DEPTH, native.BUF_SCALED_DEPTH, native.BUF_RAY_T):
+            out = np.empty((h, w), np.float32)
+        elif buffer in (native.BUF_INPUT_VERTEX, native.BUF_INPUT_NORMAL, native.BUF_MODEL_VERTEX,
+                        native.BUF_MODEL_NORMAL):
+            out = np.empty((h, w, 4), np.float32)
+        elif buffer == native.BUF_VOLUME:
+            rx, ry, _ = self.cfg.volume_resolution
+            out = np.empty((nbytes // (4 * rx * ry), ry, rx, 2), np.int16)
+        else:
+            raise ValueError("unknown buffer %r" % (buffer,))
+        assert out.nbytes == nbytes, (out.nbytes, nbytes)
+        native.check(self._L.kfh_download(self._ctx, buffer, level, out.ctypes.data_as(C.c_void_p),
+                                          C.c_size_t(nbytes)))
+        return out
+
+    def set_timing(self, enabled):
+        native.check(self._L.kfh_set_timing(self._ctx, int(bool(enabled))))
+
+    def phase_ms(self):
+        ms = np.empty(4, np.float32)
+        native.check(self._L.kfh_phase_ms(self._ctx, ms.ctypes.data_as(C.c_void_p)))
+        return ms

@@ -1,0 +1,151 @@
+"""Whole-pipeline parity: the HIP context (C ABI) against the oracle on the same synthetic stream.
+
+Bars: scheduling flags identical; buffers produced before any pose-dependent float reduction are
+bit-exact (raw depth, the TSDF while the pose is still the initial one); the trajectory stays within
+1 mm of the oracle's per frame and in ATE (north_star: ATE within 1 mm).  The two runs differ only in the
+summation order of the ICP sums (1e-7 relative); KinectFusion feeds every pose back into the model, so
+that difference grows slowly with the frame count: 1e-6 m over the first ten frames, 1e-4 m after forty
+at this coarse test resolution.
+"""
+import numpy as np
+import pytest
+
+from oracle import kf_ref
+from slambench_amd import native, synth
+from slambench_amd.config import KFusionConfig
+from slambench_amd.kfusion import KFusion
+from slambench_amd.metrics import ate
+from tests.util import oracle_config
+
+pytestmark = pytest.mark.gpu
+
+
+def _run_both(cfg, depth, use_device_frames=False, torch=None):
+    ref = kf_ref.KFusionRef(oracle_config(cfg))
+    kf = KFusion(cfg)
+    flags_ref, poses_ref = [], []
+    dev = None
+    if use_device_frames:
+        dev = torch.from_numpy(depth.view(np.int16)).cuda()
+    for i in range(depth.shape[0]):
+        flags_ref.append(ref.process_frame(depth[i]))
+        poses_ref.append(ref.pose.copy())
+        kf.process_frame(dev[i] if use_device_frames else depth[i])
+    kf.sync()
+    return ref, kf, flags_ref, np.stack(poses_ref)
+
+
+@pytest.mark.parametrize("csr,res,device_frames", [(4, 128, False), (2, 128, True)])
+def test_trajectory_matches_oracle(torch_cuda, csr, res, device_frames):
+    n = 40
+    cfg = KFusionConfig(compute_size_ratio=csr, volume_resolution=(res, res, res))
+    depth, gt, ts = synth.make_sequence(n, seed=1, noise=True)
+    ref, kf, flags_ref, poses_ref = _run_both(cfg, depth, device_frames, torch_cuda)
+    assert kf.frame == n
+    worst = 0.0
+    for f in range(n):
+        st = kf.status(f)
+        want = flags_ref[f]
+        assert (st["tracked"], st["integrated"], st["raycasted"]) == (bool(want & 1), bool(want & 2), bool(want & 4)), f
+        dpos = float(np.linalg.norm(st["pose"][:3, 3] - poses_ref[f][:3, 3]))
+        worst = max(worst, dpos)
+        if f < 10:
+            assert dpos < 1e-5, (f, dpos)
+        np.testing.assert_allclose(st["pose"][:3, :3], poses_ref[f][:3, :3], atol=1e-3)
+    # scheduling signature of the reference's kfusion logs: pose frozen for the first four frames,
+    # raycast from the fourth, integrate on frames 0-4 and then every second frame
+    assert [bool(f & 4) for f in flags_ref[:5]] == [False, False, False, True, True]
+    assert [bool(f & 2) for f in flags_ref[:9]] == [True, True, True, True, True, False, True, False, True]
+    assert worst < 1e-3, worst
+    est = np.stack([kf.status(f)["pose"] for f in range(n)])
+    a_hip = ate(est, gt, ts, ts)
+    a_ref = ate(poses_ref, gt, ts, ts)
+    assert abs(a_hip["rmse"] - a_ref["rmse"]) < 1e-3
+    assert np.allclose(kf.pose, est[-1])
+    kf.close()
+
+
+def test_buffers_match_oracle_while_pose_is_initial(torch_cuda):
+    """Frames 0-3 run with the initial pose: every buffer except the filtered pyramid is bit-exact."""
+    cfg = KFusionConfig(compute_size_ratio=4, volume_resolution=(64, 64, 64))
+    depth, gt, ts = synth.make_sequence(4, seed=3, noise=True)
+    ref, kf, flags_ref, poses_ref = _run_both(cfg, depth)
+    assert np.array_equal(kf.download(native.BUF_FLOAT_DEPTH), ref.float_depth())
+    for level in range(3):
+        got = kf.download(native.BUF_SCALED_DEPTH, level)
+        # bilateral (expf) feeds the pyramid: 1e-5 relative
+        np.testing.assert_allclose(got, ref.scaled_depth(level), rtol=1e-5)
+        v = kf.download(native.BUF_INPUT_VERTEX, level)[..., :3]
+        np.testing.assert_allclose(v, ref.input_vertex(level), rtol=1e-5, atol=1e-7)
+    assert np.array_equal(kf.download(native.BUF_VOLUME), ref.volume())
+    assert np.array_equal(kf.pose, ref.pose)
+    # the fourth frame raycasts the 4-frame TSDF from the initial pose: identical inputs -> identical maps
+    mv = kf.download(native.BUF_MODEL_VERTEX)[..., :3]
+    mn = kf.download(native.BUF_MODEL_NORMAL)[..., :3]
+    assert np.array_equal(mv, ref.model_vertex())
+    hit = ref.model_normal()[..., 0] != -2
+    assert np.array_equal(mn[hit], ref.model_normal()[hit])
+    kf.close()
+
+
+def test_tracking_rate_and_filtered_integration(torch_cuda):
+    cfg = KFusionConfig(compute_size_ratio=4, volume_resolution=(64, 64, 64), tracking_rate=2, integration_rate=3,
+                        integrate_filtered=True, pyramid=(4, 3, 2))
+    depth, gt, ts = synth.make_sequence(14, seed=2)
+    ref, kf, flags_ref, poses_ref = _run_both(cfg, depth)
+    for f in range(14):
+        st = kf.status(f)
+        want = flags_ref[f]
+        assert (st["tracked"], st["integrated"], st["raycasted"]) == (bool(want & 1), bool(want & 2), bool(want & 4)), f
+        assert np.linalg.norm(st["pose"][:3, 3] - poses_ref[f][:3, 3]) < 1e-3
+    kf.close()
+
+
+def test_reset_and_set_pose(torch_cuda):
+    cfg = KFusionConfig(compute_size_ratio=4, volume_resolution=(64, 64, 64))
+    depth, gt, ts = synth.make_sequence(6, seed=1)
+    kf = KFusion(cfg)
+    for i in range(6):
+        kf.process_frame(depth[i])
+    p1 = kf.pose.copy()
+    v1 = kf.download(native.BUF_VOLUME)
+    kf.reset()
+    assert kf.frame == 0
+    p0 = np.eye(4, dtype=np.float32)
+    p0[:3, 3] = cfg.volume_direction
+    assert np.array_equal(kf.pose, p0)
+    vol0 = kf.download(native.BUF_VOLUME)
+    assert (vol0[..., 0] == 32766).all() and (vol0[..., 1] == 0).all()
+    for i in range(6):
+        kf.process_frame(depth[i])
+    assert np.array_equal(kf.pose, p1)                       # deterministic run to run
+    assert np.array_equal(kf.download(native.BUF_VOLUME), v1)
+    q = p0.copy()
+    q[0, 3] = 4.5
+    kf.set_pose(q)
+    assert np.array_equal(kf.pose, q)
+    kf.close()
+
+
+def test_phase_timing(torch_cuda):
+    cfg = KFusionConfig(compute_size_ratio=2, volume_resolution=(128, 128, 128))
+    depth, _, _ = synth.make_sequence(6, seed=1)
+    kf = KFusion(cfg)
+    kf.set_timing(True)
+    for i in range(6):
+        kf.process_frame(depth[i])
+    ms = kf.phase_ms()
+    assert ms.shape == (4,) and (ms >= 0).all() and ms.sum() > 0
+    kf.close()
+
+
+def test_invalid_config_is_rejected(torch_cuda):
+    with pytest.raises(ValueError):
+        KFusion(KFusionConfig(compute_size_ratio=3))
+    cfg = KFusionConfig()
+    c = cfg.to_c()
+    c.vol_res[0] = 0
+    import ctypes as C
+    ctx = C.c_void_p()
+    rc = native.lib().kfh_create(C.byref(c), C.byref(ctx))
+    assert rc == 1 and not ctx.value
