@@ -1,0 +1,213 @@
+#!/usr/bin/env python3
+"""KFusion throughput benchmark on MI355X.
+
+One "step" = one depth frame through the whole hot path (preprocessing -> tracking -> integration ->
+raycasting), with the frame already resident in HBM.  Workload at N=1: BASELINE.json configs[1] —
+640x480 depth, TUM fr1 depth intrinsics, 512^3 TSDF over 8 m, ICP pyramid 10/5/4, integration-rate 2 —
+on the deterministic synthetic room stream (no dataset is available offline).  At N>1 every rank runs
+its own sequence (the reference's design-space sweeps are one process per configuration), so scaling is weak
+and there is no data-path collective.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak (spec)
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--volume", type=int, default=512, help="TSDF resolution per side")
+    ap.add_argument("--csr", type=int, default=1, help="compute-size-ratio")
+    ap.add_argument("--unique-frames", type=int, default=100,
+                    help="rendered frames; the stream plays them forwards then backwards")
+    ap.add_argument("--cpu-frames", type=int, default=12, help="frames of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--cpu-threads", type=int, default=16)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "integrate_traffic.json"),
+                    help="HBM bytes per integrate launch from the committed rocprofv3 PMC passes")
+    return ap.parse_args()
+
+
+def ping_pong(n_unique, count):
+    """Frame order 0..n-1, n-2..1, 0.. — consecutive frames are always neighbours in time."""
+    period = list(range(n_unique)) + list(range(n_unique - 2, 0, -1))
+    return [period[i % len(period)] for i in range(count)]
+
+
+def cpu_baseline(cfg, depth, frames, threads):
+    """The oracle (a port of the kfusion C++ path) timed on this box's host cores on the first frames."""
+    os.environ["OMP_NUM_THREADS"] = str(threads)
+    from oracle import kf_ref
+    ref = kf_ref.KFusionRef(cfg.to_c(kf_ref.Config))
+    poses = []
+    t0 = time.perf_counter()
+    phases = np.zeros(4)
+    for i in range(frames):
+        ref.process_frame(depth[i])
+        phases += ref.phase_seconds
+        poses.append(ref.pose.copy())
+    dt = time.perf_counter() - t0
+    ref.close()
+    return frames / dt, np.stack(poses), phases / frames
+
+
+def main():
+    a = parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("OMP_NUM_THREADS", "8")
+
+    import torch
+    import torch.distributed as dist
+    from slambench_amd import synth
+    from slambench_amd.config import KFusionConfig, TUM_FR1_DEPTH_INTRINSICS
+    from slambench_amd.kfusion import KFusion
+    from slambench_amd.metrics import ate
+
+    assert torch.cuda.is_available(), "bench.py needs a HIP device"
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    V = a.volume
+    cfg = KFusionConfig(input_size=(640, 480), intrinsics=TUM_FR1_DEPTH_INTRINSICS, compute_size_ratio=a.csr,
+                        volume_resolution=(V, V, V))
+    total = a.steps + a.warmup
+    n_unique = max(8, min(a.unique_frames, total))
+    depth, gt, ts = synth.make_sequence(n_unique, seed=1 + rank, intrinsics=TUM_FR1_DEPTH_INTRINSICS, noise=True)
+    order = ping_pong(n_unique, total)
+    d_depth = torch.from_numpy(depth.view(np.int16)).cuda()      # every frame resident in HBM
+    frame_ptrs = [int(d_depth[i].data_ptr()) for i in range(n_unique)]
+
+    kf = KFusion(cfg)
+    kf.set_timing(2)     # two HIP events per frame around the integration phase, on the pipeline's stream
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        kf.sync()
+
+    for i in range(a.warmup):
+        kf.process_frame(frame_ptrs[order[i]])
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(a.warmup, total):
+        kf.process_frame(frame_ptrs[order[i]])
+    kf.sync()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        dist.barrier()
+
+    # integrate launches of the timed region (HIP events recorded live on the pipeline's stream)
+    first = max(a.warmup, total - 500)
+    integ_ms = []
+    tracked = 0
+    for f in range(first, total):
+        st = kf.status(f)
+        tracked += int(st["tracked"])
+        if st["integrated"]:
+            integ_ms.append(float(kf.phase_ms(f)[2]))
+    integ_ms = np.asarray(integ_ms)
+    t_int = float(integ_ms.mean()) * 1e-3 if integ_ms.size else float("nan")
+    alg_bytes = 8.0 * V ** 3                       # 4 B read + 4 B written per voxel, whole volume per launch
+    achieved = alg_bytes / t_int / 1e9 if integ_ms.size else float("nan")
+
+    # accuracy on the forward part of the stream (ground truth is known for the synthetic camera)
+    n_fwd = min(total, n_unique)
+    est = np.stack([kf.status(f)["pose"] for f in range(n_fwd)]) if total <= 4096 else None
+    ate_hip = ate(est, gt[:n_fwd], ts[:n_fwd], ts[:n_fwd])["rmse"] if est is not None else None
+
+    result = None
+    if rank == 0:
+        traffic = None
+        if os.path.exists(a.traffic_json):
+            try:
+                with open(a.traffic_json) as f:
+                    tj = json.load(f)
+                if int(tj.get("volume", 0)) == V:
+                    traffic = tj.get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        result = {
+            "metric": "KFusion frames/s @640x480 512^3 TSDF; integrate GVox/s; ATE delta vs ref",
+            "value": world * a.steps / elapsed,
+            "unit": "frames/s",
+            "n_gpus": world,
+            "steps": a.steps,
+            "warmup": a.warmup,
+            "ms_per_step": elapsed / a.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": "KFusion 640x480 depth (TUM fr1 intrinsics), %d^3 TSDF over 8 m, ICP 10/5/4, "
+                            "integration-rate 2, synthetic room stream (configs[1])" % V,
+                "compute_size": "%dx%d" % cfg.compute_size, "volume": V,
+                "parallelism": "1 sequence per GPU (replicas, no collective)" if world > 1 else "single GPU",
+            },
+            "integrate_gvox_per_s": (V ** 3 / t_int / 1e9) if integ_ms.size else None,
+            "integrate_ms": t_int * 1e3 if integ_ms.size else None,
+            "tracked_fraction": tracked / max(1, total - first),
+            "ate_rmse_m": ate_hip,
+            "roofline": {
+                "kernel": "k_integrate",
+                "bound": "hbm",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS if integ_ms.size else None,
+                "traffic": traffic,
+                "note": "achieved = 8 B x V^3 per launch (convention: every voxel read and written) / mean "
+                        "HIP-event duration of the integrate launches in the timed region; the kernel skips "
+                        "voxels outside the camera frustum or behind the surface without touching them, so "
+                        "measured traffic is below the algorithmic bytes and frac may exceed 1",
+            },
+        }
+        if not a.no_cpu_baseline and a.cpu_frames > 0 and world == 1:
+            threads = max(1, min(a.cpu_threads, os.cpu_count() or 1))
+            n_cpu = min(a.cpu_frames, n_unique)
+            fps_cpu, poses_cpu, phases = cpu_baseline(cfg, depth, n_cpu, threads)
+            d = np.linalg.norm(est[:n_cpu, :3, 3] - poses_cpu[:, :3, 3], axis=1) if est is not None else None
+            a_cpu = ate(poses_cpu, gt[:n_cpu], ts[:n_cpu], ts[:n_cpu])["rmse"]
+            a_hip = ate(est[:n_cpu], gt[:n_cpu], ts[:n_cpu], ts[:n_cpu])["rmse"] if est is not None else None
+            result["cpu_baseline"] = {
+                "value": fps_cpu, "unit": "frames/s", "cores": threads, "kind": "port",
+                "sample": "first %d frames of the same stream (same config) through the CPU oracle, OpenMP" % n_cpu,
+                "phase_seconds": {"preprocessing": phases[0], "tracking": phases[1], "integration": phases[2],
+                                  "raycasting": phases[3]},
+            }
+            result["ate_delta_vs_cpu_m"] = abs(a_hip - a_cpu) if a_hip is not None else None
+            result["max_position_delta_vs_cpu_m"] = float(d.max()) if d is not None else None
+    kf.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(result))
+
+
+if __name__ == "__main__":
+    main()

@@ -74,6 +74,8 @@ typedef struct kfh_frame_status {
     int32_t raycasted;    /* the model maps were re-rendered                    */
     float   pose[16];     /* pose after the frame                               */
     float   sums[32];     /* last ICP reduction (layout of reduceKernel)        */
+    int32_t icp_iterations; /* ICP iterations executed in this frame (all levels) */
+    int32_t slow_solves;    /* of those, solves that needed the eigen-decomposition path */
 } kfh_frame_status;
 
 typedef struct kfh_context kfh_context;
@@ -121,9 +123,12 @@ int kfh_compute_size(kfh_context *ctx, int *w, int *h);
 int kfh_download(kfh_context *ctx, int buffer, int level, void *h_dst, size_t bytes);
 int kfh_device_ptr(kfh_context *ctx, int buffer, int level, void **d_ptr, size_t *bytes);
 int kfh_stream(kfh_context *ctx, void **stream);
-/* event timing of the four phases of the most recent frame processed with timing enabled */
-int kfh_set_timing(kfh_context *ctx, int enabled);
-int kfh_phase_ms(kfh_context *ctx, float ms[4]);
+/* HIP-event timing on the context's stream.  mode 0: off; 1: all four phases of every frame;
+ * 2: the integration phase only (two events per frame).  Records of the last 512 frames are kept;
+ * ms = {preprocessing, tracking, integration, raycasting}; both getters synchronise. */
+int kfh_set_timing(kfh_context *ctx, int mode);
+int kfh_phase_ms(kfh_context *ctx, float ms[4]);                 /* most recent frame */
+int kfh_phase_ms_frame(kfh_context *ctx, int frame, float ms[4]);
 
 /* ---- z-slab sharding across devices (one context per device) ---- */
 /* March only this context's slab; writes hit distance t (0 = miss), vertex and normal of the nearest
@@ -153,7 +158,8 @@ int kfh_k_track_reduce(float *d_sums, kfh_track_data *d_track, int track_stride,
                        const void *d_ref_vertex4, const void *d_ref_normal4, int rw, int rh,
                        const float Ttrack[16], const float view[16],
                        float dist_threshold, float normal_threshold, void *stream);
-/* solve + updatePoseKernel on the device: pose <- exp(x) * pose, x (6 doubles) and converged flag out. */
+/* solve + updatePoseKernel on the device: pose <- exp(x) * pose; d_x6 receives the twist (6 doubles),
+ * d_converged two ints: {|x| < icp_threshold, 1 if the eigen-decomposition path was needed}. */
 int kfh_k_update_pose(float *d_pose16, double *d_x6, int *d_converged, const float *d_sums,
                       float icp_threshold, void *stream);
 /* integrateKernel over z in [z0, z1) of a volume whose storage starts at plane z0 */

@@ -70,14 +70,18 @@ struct kfh_context {
     float *d_ray_t = nullptr;
     short2 *d_volume = nullptr;
     size_t volume_voxels = 0;
-    float *d_partials = nullptr;
+    float *d_partials = nullptr;           // two alternating buffers of per-block partial rows
+    size_t partials_stride = 0;            // floats per buffer
     Ctrl *d_ctrl = nullptr;
     kfh_frame_status *d_status = nullptr;
 
-    bool timing = false;
-    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-    bool ev_valid = false;
+    // phase timing: a ring of event sets, one per frame (slot = frame % KFH_TIMING_RING)
+    int timing = 0;            // 0 off, 1 all four phases, 2 integration only
+    hipEvent_t (*ev)[5] = nullptr;
+    int timed_first = -1;      // first frame recorded since timing was (re)enabled
 };
+
+constexpr int KFH_TIMING_RING = 512;
 
 namespace {
 
@@ -115,8 +119,12 @@ void free_all(kfh_context *c) {
                     c->d_partials, c->d_ctrl, c->d_status};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
-    for (auto &e : c->ev)
-        if (e) (void)hipEventDestroy(e);
+    if (c->ev) {
+        for (int i = 0; i < KFH_TIMING_RING; ++i)
+            for (int j = 0; j < 5; ++j)
+                if (c->ev[i][j]) (void)hipEventDestroy(c->ev[i][j]);
+        delete[] c->ev;
+    }
     if (c->stream) (void)hipStreamDestroy(c->stream);
 }
 
@@ -137,15 +145,16 @@ int init_state(kfh_context *c) {
     KFH_HIP(launch_pose_derive(c->d_ctrl, c->k, 1, c->stream));
     c->frame = 0;
     c->d_depth_cur = c->d_depth_in;
-    c->ev_valid = false;
+    c->timed_first = -1;
     return KFH_OK;
 }
 
-SolveArgs solve_args(const kfh_context *c) {
-    SolveArgs a;
+FinishArgs finish_args(const kfh_context *c, int seq) {
+    FinishArgs a;
     std::memset(&a, 0, sizeof(a));
     a.ctrl = c->d_ctrl;
-    a.partials = c->d_partials;
+    a.partials_in = c->d_partials + (size_t)(seq & 1) * c->partials_stride;
+    a.seq = seq;
     a.w = c->w;
     a.h = c->h;
     a.icp_threshold = c->cfg.icp_threshold;
@@ -210,10 +219,10 @@ int kfh_create(const kfh_config *cfg, kfh_context **out) {
     if (e == hipSuccess) e = dev_alloc(&c->d_normal, npix);
     if (e == hipSuccess) e = dev_alloc(&c->d_ray_t, npix);
     if (e == hipSuccess) e = dev_alloc(&c->d_volume, c->volume_voxels);
-    if (e == hipSuccess) e = dev_alloc(&c->d_partials, (size_t)track_blocks(c->w, c->h) * 32);
+    c->partials_stride = (size_t)track_blocks(c->w, c->h) * 32;
+    if (e == hipSuccess) e = dev_alloc(&c->d_partials, 2 * c->partials_stride);
     if (e == hipSuccess) e = dev_alloc(&c->d_ctrl, 1);
     if (e == hipSuccess) e = dev_alloc(&c->d_status, KFH_STATUS_RING);
-    for (int i = 0; i < 5 && e == hipSuccess; ++i) e = hipEventCreate(&c->ev[i]);
     if (e != hipSuccess) {
         free_all(c);
         delete c;
@@ -260,21 +269,19 @@ int kfh_set_depth_device(kfh_context *c, const uint16_t *d_depth) {
 
 int kfh_preprocess(kfh_context *c) {
     KFH_REQUIRE(c != nullptr, "context is NULL");
-    if (c->timing) KFH_HIP(hipEventRecord(c->ev[0], c->stream));
+    if (c->timing == 1) KFH_HIP(hipEventRecord(c->ev[c->frame % KFH_TIMING_RING][0], c->stream));
     KFH_HIP(launch_preprocess(c->d_float_depth, c->d_scaled[0], c->w, c->h, c->d_depth_cur, true,
                               c->cfg.input_width, c->cfg.compute_size_ratio, c->cfg.depth_divisor, c->stream));
-    if (c->timing) KFH_HIP(hipEventRecord(c->ev[1], c->stream));
+    if (c->timing == 1) KFH_HIP(hipEventRecord(c->ev[c->frame % KFH_TIMING_RING][1], c->stream));
     return KFH_OK;
 }
 
 int kfh_track(kfh_context *c) {
     KFH_REQUIRE(c != nullptr, "context is NULL");
-    SolveArgs a = solve_args(c);
-    int final_level = -1;
-    for (int l = 0; l < 3; ++l)
-        if (c->cfg.pyramid[l] > 0) { final_level = l; break; }
-    if (c->frame % c->cfg.tracking_rate != 0 || final_level < 0) {
-        KFH_HIP(launch_track_skip(a, c->stream));
+    int total_iterations = 0;
+    for (int l = 0; l < 3; ++l) total_iterations += c->cfg.pyramid[l];
+    if (c->frame % c->cfg.tracking_rate != 0 || total_iterations == 0) {
+        KFH_HIP(launch_track_skip(finish_args(c, 0), c->stream));
     } else {
         for (int l = 1; l < 3; ++l)
             KFH_HIP(launch_half_sample(c->d_scaled[l], c->d_scaled[l - 1], c->w >> (l - 1), c->h >> (l - 1),
@@ -284,23 +291,34 @@ int kfh_track(kfh_context *c) {
             KFH_HIP(launch_vertex_normal(c->d_in_vertex[l], c->d_in_normal[l], c->d_scaled[l], c->w >> l,
                                          c->h >> l, c->k[0] / s, c->k[1] / s, c->k[2] / s, c->k[3] / s, c->stream));
         }
+        IcpIterArgs a;
+        std::memset(&a, 0, sizeof(a));
+        a.ctrl = c->d_ctrl;
+        a.ref_vertex = c->d_vertex;
+        a.ref_normal = c->d_normal;
+        a.rw = c->w;
+        a.rh = c->h;
+        a.dist_threshold = DIST_THRESHOLD;
+        a.normal_threshold = NORMAL_THRESHOLD;
+        a.icp_threshold = c->cfg.icp_threshold;
+        int seq = 0;
         for (int level = 2; level >= 0; --level) {
-            const int lw = c->w >> level, lh = c->h >> level;
-            const int nb = track_blocks(lw, lh);
-            for (int i = 0; i < c->cfg.pyramid[level]; ++i) {
-                KFH_HIP(launch_track_reduce(c->d_partials, nullptr, 0, c->d_in_vertex[level], c->d_in_normal[level],
-                                            lw, lh, c->d_vertex, c->d_normal, c->w, c->h, &c->d_ctrl->pose,
-                                            &c->d_ctrl->project_ref, DIST_THRESHOLD, NORMAL_THRESHOLD,
-                                            &c->d_ctrl->level_done[level], c->frame + 1, c->stream));
-                a.nblocks = nb;
-                a.level = level;
-                a.last_iter_of_level = (i == c->cfg.pyramid[level] - 1) ? 1 : 0;
-                a.final_level = (level == final_level) ? 1 : 0;
-                KFH_HIP(launch_icp_solve(a, c->stream));
+            a.level = level;
+            a.in_vertex = c->d_in_vertex[level];
+            a.in_normal = c->d_in_normal[level];
+            a.iw = c->w >> level;
+            a.ih = c->h >> level;
+            for (int i = 0; i < c->cfg.pyramid[level]; ++i, ++seq) {
+                a.seq = seq;
+                a.last_iter = (i == c->cfg.pyramid[level] - 1) ? 1 : 0;
+                a.partials_in = c->d_partials + (size_t)(seq & 1) * c->partials_stride;
+                a.partials_out = c->d_partials + (size_t)((seq + 1) & 1) * c->partials_stride;
+                KFH_HIP(launch_icp_iteration(a, c->stream));
             }
         }
+        KFH_HIP(launch_icp_finish(finish_args(c, seq), c->stream));
     }
-    if (c->timing) KFH_HIP(hipEventRecord(c->ev[2], c->stream));
+    if (c->timing) KFH_HIP(hipEventRecord(c->ev[c->frame % KFH_TIMING_RING][2], c->stream));
     return KFH_OK;
 }
 
@@ -313,7 +331,7 @@ int kfh_integrate(kfh_context *c) {
                                  &c->d_ctrl->inv_pose, camera_matrix(c->k[0], c->k[1], c->k[2], c->k[3]),
                                  c->cfg.mu, MAX_WEIGHT, &c->d_ctrl->integrate_gate, c->stream));
     }
-    if (c->timing) KFH_HIP(hipEventRecord(c->ev[3], c->stream));
+    if (c->timing) KFH_HIP(hipEventRecord(c->ev[c->frame % KFH_TIMING_RING][3], c->stream));
     return KFH_OK;
 }
 
@@ -332,10 +350,8 @@ int kfh_raycast(kfh_context *c) {
                                c->cfg.vol_dim, 0, c->cfg.vol_res[2], &c->d_ctrl->view, NEAR_PLANE, FAR_PLANE,
                                raycast_step(c->cfg), 0.75f * c->cfg.mu, c->stream));
     }
-    if (c->timing) {
-        KFH_HIP(hipEventRecord(c->ev[4], c->stream));
-        c->ev_valid = true;
-    }
+    if (c->timing == 1) KFH_HIP(hipEventRecord(c->ev[c->frame % KFH_TIMING_RING][4], c->stream));
+    if (c->timing && c->timed_first < 0) c->timed_first = c->frame;
     return KFH_OK;
 }
 
@@ -453,19 +469,40 @@ int kfh_stream(kfh_context *c, void **stream) {
     return KFH_OK;
 }
 
-int kfh_set_timing(kfh_context *c, int enabled) {
+int kfh_set_timing(kfh_context *c, int mode) {
     KFH_REQUIRE(c != nullptr, "context is NULL");
-    c->timing = enabled != 0;
-    c->ev_valid = false;
+    KFH_REQUIRE(mode >= 0 && mode <= 2, "timing mode must be 0, 1 or 2");
+    if (mode != 0 && !c->ev) {
+        c->ev = new (std::nothrow) hipEvent_t[KFH_TIMING_RING][5]();
+        if (!c->ev) return fail(KFH_ERR_STATE, "out of host memory");
+        for (int i = 0; i < KFH_TIMING_RING; ++i)
+            for (int j = 0; j < 5; ++j) KFH_HIP(hipEventCreate(&c->ev[i][j]));
+    }
+    c->timing = mode;
+    c->timed_first = -1;
+    return KFH_OK;
+}
+
+int kfh_phase_ms_frame(kfh_context *c, int frame, float ms[4]) {
+    KFH_REQUIRE(c != nullptr && ms != nullptr, "NULL argument");
+    if (!c->timing || c->timed_first < 0)
+        return fail(KFH_ERR_STATE, "no frame has been processed with timing enabled");
+    KFH_REQUIRE(frame >= c->timed_first && frame < c->frame && frame >= c->frame - KFH_TIMING_RING,
+                "frame %d has no retained timing record", frame);
+    KFH_HIP(hipStreamSynchronize(c->stream));
+    hipEvent_t *e = c->ev[frame % KFH_TIMING_RING];
+    for (int i = 0; i < 4; ++i) ms[i] = 0.f;
+    if (c->timing == 1) {
+        for (int i = 0; i < 4; ++i) KFH_HIP(hipEventElapsedTime(&ms[i], e[i], e[i + 1]));
+    } else {
+        KFH_HIP(hipEventElapsedTime(&ms[2], e[2], e[3]));
+    }
     return KFH_OK;
 }
 
 int kfh_phase_ms(kfh_context *c, float ms[4]) {
-    KFH_REQUIRE(c != nullptr && ms != nullptr, "NULL argument");
-    if (!c->ev_valid) return fail(KFH_ERR_STATE, "no frame has been processed with timing enabled");
-    KFH_HIP(hipEventSynchronize(c->ev[4]));
-    for (int i = 0; i < 4; ++i) KFH_HIP(hipEventElapsedTime(&ms[i], c->ev[i], c->ev[i + 1]));
-    return KFH_OK;
+    KFH_REQUIRE(c != nullptr, "context is NULL");
+    return kfh_phase_ms_frame(c, c->frame - 1, ms);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -512,17 +549,18 @@ int kfh_k_track_reduce(float *d_sums, kfh_track_data *d_track, int track_stride,
     KFH_REQUIRE(!d_track || track_stride >= iw, "track_stride must be >= iw");
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int nb = track_blocks(iw, ih);
-    float *scratch = nullptr;   // [2 matrices | partials]
-    KFH_HIP(hipMalloc(reinterpret_cast<void **>(&scratch), (32 + (size_t)nb * 32) * sizeof(float)));
-    hipError_t e = hipMemcpyAsync(scratch, Ttrack, 16 * sizeof(float), hipMemcpyHostToDevice, s);
-    if (e == hipSuccess) e = hipMemcpyAsync(scratch + 16, view, 16 * sizeof(float), hipMemcpyHostToDevice, s);
-    if (e == hipSuccess)
-        e = launch_track_reduce(scratch + 32, d_track, track_stride, static_cast<const float4 *>(d_in_vertex4),
-                                static_cast<const float4 *>(d_in_normal4), iw, ih,
-                                static_cast<const float4 *>(d_ref_vertex4), static_cast<const float4 *>(d_ref_normal4),
-                                rw, rh, reinterpret_cast<const Mat4 *>(scratch), reinterpret_cast<const Mat4 *>(scratch + 16),
-                                dist_threshold, normal_threshold, nullptr, 0, s);
-    if (e == hipSuccess) e = launch_sum_partials(d_sums, scratch + 32, nb, s);
+    char *scratch = nullptr;   // [control block | partial rows]
+    const size_t ctrl_bytes = (sizeof(Ctrl) + 255) & ~(size_t)255;
+    KFH_HIP(hipMalloc(reinterpret_cast<void **>(&scratch), ctrl_bytes + (size_t)nb * 32 * sizeof(float)));
+    Mat4 T, V;
+    std::memcpy(T.m, Ttrack, sizeof(T.m));
+    std::memcpy(V.m, view, sizeof(V.m));
+    hipError_t e = launch_track_reduce(reinterpret_cast<Ctrl *>(scratch), reinterpret_cast<float *>(scratch + ctrl_bytes),
+                                       d_sums, d_track, track_stride, static_cast<const float4 *>(d_in_vertex4),
+                                       static_cast<const float4 *>(d_in_normal4), iw, ih,
+                                       static_cast<const float4 *>(d_ref_vertex4),
+                                       static_cast<const float4 *>(d_ref_normal4), rw, rh, T, V, dist_threshold,
+                                       normal_threshold, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     (void)hipFree(scratch);
     KFH_HIP(e);

@@ -7,6 +7,19 @@
 
 namespace kfh {
 
+// State of the ICP loop between two iteration launches (see k_icp_iteration).
+struct IcpState {
+    Mat4 pose;            // estimate after the last finalised iteration
+    float sums[32];       // reduction of the last finalised iteration
+    int pending_nblocks;  // partial rows written by the previous launch that still await their solve
+    int pending_level;    // pyramid level of that iteration
+    int pending_last;     // it was the last iteration configured for its level
+    int done_mask;        // bit l: level l finished (converged or exhausted) in this frame
+    int iterations;       // iterations finalised in this frame
+    int slow_solves;      // of those, solves that needed the eigen-decomposition path
+    int pad_[2];
+};
+
 // Device-resident control block of one pipeline context.  The host never needs to read it inside a
 // frame: every decision that depends on tracking results is taken by the kernels themselves.
 struct Ctrl {
@@ -17,22 +30,15 @@ struct Ctrl {
     Mat4 inv_pose;      // inverse(pose), input of integrate
     Mat4 view;          // pose * inverse(K), input of raycast
     float sums[32];     // last ICP reduction
-    double x[6];        // last twist
-    int level_done[4];  // frame + 1 of the frame in which the ICP level finished (converged or exhausted)
     int tracked;        // result of the pose check of this frame
-    int integrate_gate; // tracked, or frame <= 3
+    int integrate_gate; // this frame fuses its depth map: (tracked and rate hit) or frame <= 3
     int frame;          // frame counter (device copy)
     int pad_;
+    IcpState icp[2];    // alternating records of the ICP loop
 };
 
-struct IcpLevel {
-    const float4 *in_vertex;
-    const float4 *in_normal;
-    int w, h;
-};
-
-constexpr int KFH_TRACK_THREADS = 256;
-constexpr int KFH_TRACK_PIX_PER_THREAD = 4;
+constexpr int KFH_TRACK_THREADS = 512;
+constexpr int KFH_TRACK_PIX_PER_THREAD = 2;
 constexpr int KFH_STATUS_RING = 4096;
 
 inline int track_blocks(int w, int h) {
@@ -40,28 +46,25 @@ inline int track_blocks(int w, int h) {
     return (w * h + per_block - 1) / per_block;
 }
 
-hipError_t launch_preprocess(float *raw, float *filtered, int ow, int oh, const void *in, bool in_is_u16,
-                             int iw, int ratio, float divisor, hipStream_t s);
-hipError_t launch_half_sample(float *out, const float *in, int iw, int ih, float e_d, hipStream_t s);
-hipError_t launch_vertex_normal(float4 *vertex, float4 *normal, const float *depth, int w, int h, float fx,
-                                float fy, float cx, float cy, hipStream_t s);
-// one ICP iteration, part 1: residuals + per-block partial sums.  `done_flag` (may be null) makes the
-// kernel a no-op when *done_flag == done_value.
-hipError_t launch_track_reduce(float *partials, kfh_track_data *track_out, int track_stride,
-                               const float4 *in_vertex, const float4 *in_normal, int iw, int ih,
-                               const float4 *ref_vertex, const float4 *ref_normal, int rw, int rh,
-                               const Mat4 *Ttrack, const Mat4 *view, float dist_threshold,
-                               float normal_threshold, const int *done_flag, int done_value, hipStream_t s);
-// part 2: fixed-order sum of the partials into sums[32]
-hipError_t launch_sum_partials(float *sums, const float *partials, int nblocks, hipStream_t s);
-// part 2 of a pipeline iteration: sum, solve, update pose, convergence, optional pose check + derived matrices
-struct SolveArgs {
+struct IcpIterArgs {
     Ctrl *ctrl;
-    const float *partials;
-    int nblocks;
-    int level;
-    int last_iter_of_level;   // set level_done after this iteration regardless of convergence
-    int final_level;          // this level ends tracking: run the pose check when the level finishes
+    const float *partials_in;   // rows of the previous iteration launch
+    float *partials_out;        // rows of this one
+    int seq;                    // position of this launch in the frame's iteration sequence
+    int level, last_iter;       // pyramid level; last iteration configured for the level
+    const float4 *in_vertex, *in_normal;
+    int iw, ih;
+    const float4 *ref_vertex, *ref_normal;
+    int rw, rh;
+    float dist_threshold, normal_threshold, icp_threshold;
+    kfh_track_data *track_out;  // per-pixel TrackData for parity tests, may be null
+    int track_stride;
+};
+
+struct FinishArgs {
+    Ctrl *ctrl;
+    const float *partials_in;
+    int seq;                  // number of iteration launches of this frame
     int w, h;                 // compute size (pose check normalisation)
     float icp_threshold;
     float track_threshold;
@@ -71,9 +74,23 @@ struct SolveArgs {
     int integration_rate;
     kfh_frame_status *status_ring;
 };
-hipError_t launch_icp_solve(const SolveArgs &a, hipStream_t s);
+
+hipError_t launch_preprocess(float *raw, float *filtered, int ow, int oh, const void *in, bool in_is_u16,
+                             int iw, int ratio, float divisor, hipStream_t s);
+hipError_t launch_half_sample(float *out, const float *in, int iw, int ih, float e_d, hipStream_t s);
+hipError_t launch_vertex_normal(float4 *vertex, float4 *normal, const float *depth, int w, int h, float fx,
+                                float fy, float cx, float cy, hipStream_t s);
+hipError_t launch_icp_iteration(const IcpIterArgs &a, hipStream_t s);
+hipError_t launch_icp_finish(const FinishArgs &a, hipStream_t s);
 // tracking skipped (tracking-rate) or no iterations configured: record "not tracked" and derive matrices
-hipError_t launch_track_skip(const SolveArgs &a, hipStream_t s);
+hipError_t launch_track_skip(const FinishArgs &a, hipStream_t s);
+// one stand-alone iteration on caller-provided matrices + fixed-order sum of its partial rows (parity tests)
+hipError_t launch_track_reduce(Ctrl *scratch_ctrl, float *partials, float *sums, kfh_track_data *track_out,
+                               int track_stride, const float4 *in_vertex, const float4 *in_normal, int iw, int ih,
+                               const float4 *ref_vertex, const float4 *ref_normal, int rw, int rh,
+                               const Mat4 &Ttrack, const Mat4 &view, float dist_threshold, float normal_threshold,
+                               hipStream_t s);
+hipError_t launch_sum_partials(float *sums, const float *partials, int nrows, hipStream_t s);
 hipError_t launch_update_pose(float *pose16, double *x6, int *converged, const float *sums, float thr,
                               hipStream_t s);
 hipError_t launch_pose_derive(Ctrl *ctrl, const float k[4], int set_raycast_pose, hipStream_t s);

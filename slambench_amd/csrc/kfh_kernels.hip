@@ -7,6 +7,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <cmath>
+
 namespace kfh {
 
 // =====================================================================================================
@@ -164,267 +166,195 @@ hipError_t launch_vertex_normal(float4 *vertex, float4 *normal, const float *dep
 }
 
 // =====================================================================================================
-// trackKernel + reduceKernel fused.  Each thread evaluates KFH_TRACK_PIX_PER_THREAD pixels and keeps the
-// 32 sums in registers; a wavefront shuffle tree and a 4-wave LDS stage produce one 32-float partial per
-// block.  Row layout: [0] sum e^2, [1..6] sum e*J, [7..27] upper triangle of sum J J^T, [28] valid,
+// trackKernel + reduceKernel fused.  Each thread evaluates KFH_TRACK_PIX_PER_THREAD pixels; all input
+// loads are issued before the projections and all reference gathers before the residuals, so one thread
+// exposes two memory round trips, not two per pixel.  The 32 sums stay in registers; a DPP wavefront
+// reduction and an LDS stage across the block's waves produce one 32-float partial per block.
+// Row layout: [0] sum e^2, [1..6] sum e*J, [7..27] upper triangle of sum J J^T, [28] valid,
 // [29] result==-4, [30] result==-5, [31] result in {-1,-2,-3}.
 // Algorithmic bytes: 64 B per pixel (in vertex+normal, gathered reference vertex+normal) + 128 B per block.
 // =====================================================================================================
-__device__ inline float wave_sum(float v) {
+template <int CTRL, int ROW_MASK>
+__device__ inline float dpp_add(float v) {
+    const int moved = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xF, false);
+    return v + __builtin_bit_cast(float, moved);
+}
+
+// Sum over the 64 lanes of a wavefront; the total is valid in lane 63.
+__device__ inline float wave_sum_to_lane63(float v) {
+    v = dpp_add<0xB1, 0xF>(v);    // quad_perm [1,0,3,2]
+    v = dpp_add<0x4E, 0xF>(v);    // quad_perm [2,3,0,1]
+    v = dpp_add<0x114, 0xF>(v);   // row_shr:4
+    v = dpp_add<0x118, 0xF>(v);   // row_shr:8   -> lane 15 of each row holds the row sum
+    v = dpp_add<0x142, 0xA>(v);   // row_bcast:15 into rows 1 and 3
+    v = dpp_add<0x143, 0xC>(v);   // row_bcast:31 into rows 2 and 3
+    return v;
+}
+
+// Fixed-order sum of per-block partial rows by one block of NT threads: NT/32 interleaved chains
+// (rows c, c + NT/32, ...) added in chain order, so the result does not depend on scheduling.
+// lds must hold NT floats; the 32 sums are left in lds[0..31].
+template <int NT>
+__device__ inline void sum_partials_block(float *lds, const float *__restrict__ partials, int nrows) {
+    constexpr int CHAINS = NT / 32;
+    const int col = threadIdx.x & 31, chain = threadIdx.x >> 5;
+    float v = 0.f;
+    int b = chain;
+    for (; b + 3 * CHAINS < nrows; b += 4 * CHAINS) {      // four loads in flight, added in row order
+        float t[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) t[u] = partials[(b + CHAINS * u) * 32 + col];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v += t[u];
+    }
+    for (; b < nrows; b += CHAINS) v += partials[b * 32 + col];
+    lds[chain * 32 + col] = v;
+    __syncthreads();
+    if (threadIdx.x < 32) {
+        float t = lds[col];
+        for (int c = 1; c < CHAINS; ++c) t += lds[c * 32 + col];
+        lds[col] = t;
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(KFH_TRACK_THREADS) void k_sum_partials(float *sums, const float *partials, int nrows) {
+    __shared__ float lds[KFH_TRACK_THREADS];
+    sum_partials_block<KFH_TRACK_THREADS>(lds, partials, nrows);
+    if (threadIdx.x < 32) sums[threadIdx.x] = lds[threadIdx.x];
+}
+
+hipError_t launch_sum_partials(float *sums, const float *partials, int nrows, hipStream_t s) {
+    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(KFH_TRACK_THREADS), 0, s, sums, partials, nrows);
+    return hipGetLastError();
+}
+
+// =====================================================================================================
+// solve + updatePoseKernel + checkPoseKernel on the device, double precision, one wavefront.
+// The reference solves the 6x6 normal equations with an SVD back-substitution that zeroes singular
+// values below sigma_max / 1e6.  For a symmetric positive definite system whose condition number is
+// provably below 1e6 that is the plain solution.  The wavefront holds the augmented system [C | b] and
+// the identity one element per lane (lane = 8*row + column) and runs Gauss-Jordan elimination with
+// cross-lane reads, which yields x = C^-1 b and C^-1 together; cond_2(C) <= ||C||_F * ||C^-1||_F
+// certifies the result.  Otherwise lane 0 applies the truncation rule literally through a cyclic Jacobi
+// eigen-decomposition (slow path: rank-deficient or nearly singular systems).
+// =====================================================================================================
+__device__ inline double wave_sum_f64(double v) {
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
     return v;
 }
 
-__global__ __launch_bounds__(KFH_TRACK_THREADS) void k_track_reduce(
-    float *__restrict__ partials, kfh_track_data *__restrict__ track_out, int track_stride,
-    const float4 *__restrict__ in_vertex, const float4 *__restrict__ in_normal, int iw, int ih,
-    const float4 *__restrict__ ref_vertex, const float4 *__restrict__ ref_normal, int rw, int rh,
-    const Mat4 *__restrict__ Ttrack_p, const Mat4 *__restrict__ view_p, float dist_threshold,
-    float normal_threshold, const int *__restrict__ done_flag, int done_value) {
-    if (done_flag && *done_flag == done_value) return;
-    const Mat4 Ttrack = *Ttrack_p;
-    const Mat4 view = *view_p;
-    float acc[32];
-#pragma unroll
-    for (int i = 0; i < 32; ++i) acc[i] = 0.0f;
-
-    const int npix = iw * ih;
-    const int base = blockIdx.x * (KFH_TRACK_THREADS * KFH_TRACK_PIX_PER_THREAD) + threadIdx.x;
-#pragma unroll
-    for (int k = 0; k < KFH_TRACK_PIX_PER_THREAD; ++k) {
-        const int p = base + k * KFH_TRACK_THREADS;
-        if (p >= npix) break;
-        const int y = p / iw, x = p - y * iw;
-        int result;
-        float error = 0.f;
-        float J[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        const float4 nin4 = in_normal[p];
-        if (nin4.x == KFH_INVALID) {
-            result = -1;
-        } else {
-            const float4 vin4 = in_vertex[p];
-            const f3 projectedVertex = xform(Ttrack, mk3(vin4.x, vin4.y, vin4.z));
-            const f3 projectedPos = xform(view, projectedVertex);
-            const float px = projectedPos.x / projectedPos.z + 0.5f;
-            const float py = projectedPos.y / projectedPos.z + 0.5f;
-            if (px < 0 || px > rw - 1 || py < 0 || py > rh - 1) {
-                result = -2;
-            } else {
-                const unsigned rx = (unsigned)px, ry = (unsigned)py;
-                const float4 rn4 = ref_normal[rx + ry * rw];
-                if (rn4.x == KFH_INVALID) {
-                    result = -3;
-                } else {
-                    const float4 rv4 = ref_vertex[rx + ry * rw];
-                    const f3 referenceNormal = mk3(rn4.x, rn4.y, rn4.z);
-                    const f3 diff = mk3(rv4.x, rv4.y, rv4.z) - projectedVertex;
-                    const f3 projectedNormal = rotate(Ttrack, mk3(nin4.x, nin4.y, nin4.z));
-                    if (length3(diff) > dist_threshold) {
-                        result = -4;
-                    } else if (dot3(projectedNormal, referenceNormal) < normal_threshold) {
-                        result = -5;
-                    } else {
-                        result = 1;
-                        error = dot3(referenceNormal, diff);
-                        const f3 c = cross3(projectedVertex, referenceNormal);
-                        J[0] = referenceNormal.x; J[1] = referenceNormal.y; J[2] = referenceNormal.z;
-                        J[3] = c.x; J[4] = c.y; J[5] = c.z;
-                    }
-                }
-            }
-        }
-        if (track_out) {
-            kfh_track_data td;
-            td.result = result;
-            td.error = error;
-            for (int i = 0; i < 6; ++i) td.J[i] = J[i];
-            track_out[x + y * track_stride] = td;
-        }
-        if (result < 1) {
-            acc[29] += result == -4 ? 1.f : 0.f;
-            acc[30] += result == -5 ? 1.f : 0.f;
-            acc[31] += result > -4 ? 1.f : 0.f;
-        } else {
-            acc[0] += error * error;
-#pragma unroll
-            for (int i = 0; i < 6; ++i) acc[1 + i] += error * J[i];
-            int q = 7;
-#pragma unroll
-            for (int i = 0; i < 6; ++i)
-#pragma unroll
-                for (int j = i; j < 6; ++j) acc[q++] += J[i] * J[j];
-            acc[28] += 1.f;
-        }
-    }
-
-    __shared__ float wsum[KFH_TRACK_THREADS / 64][32];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-    for (int i = 0; i < 32; ++i) {
-        const float v = wave_sum(acc[i]);
-        if (lane == 0) wsum[wave][i] = v;
-    }
-    __syncthreads();
-    if (threadIdx.x < 32) {
-        float v = wsum[0][threadIdx.x];
-#pragma unroll
-        for (int wv = 1; wv < KFH_TRACK_THREADS / 64; ++wv) v += wsum[wv][threadIdx.x];
-        partials[blockIdx.x * 32 + threadIdx.x] = v;
-    }
-}
-
-hipError_t launch_track_reduce(float *partials, kfh_track_data *track_out, int track_stride,
-                               const float4 *in_vertex, const float4 *in_normal, int iw, int ih,
-                               const float4 *ref_vertex, const float4 *ref_normal, int rw, int rh,
-                               const Mat4 *Ttrack, const Mat4 *view, float dist_threshold,
-                               float normal_threshold, const int *done_flag, int done_value,
-                               hipStream_t s) {
-    const int nb = track_blocks(iw, ih);
-    hipLaunchKernelGGL(k_track_reduce, dim3(nb), dim3(KFH_TRACK_THREADS), 0, s, partials, track_out,
-                       track_stride, in_vertex, in_normal, iw, ih, ref_vertex, ref_normal, rw, rh, Ttrack,
-                       view, dist_threshold, normal_threshold, done_flag, done_value);
-    return hipGetLastError();
-}
-
-// Fixed-order sum of the per-block partials: 8 interleaved chains (blocks b, b+8, ...) added in order
-// 0..7, so the result does not depend on scheduling.
-__device__ inline void sum_partials_block(float *sums_lds /*[8][32]*/, const float *partials, int nblocks) {
-    const int col = threadIdx.x & 31, chain = threadIdx.x >> 5;   // 256 threads = 8 chains x 32 columns
-    float v = 0.f;
-    for (int b = chain; b < nblocks; b += 8) v += partials[b * 32 + col];
-    sums_lds[chain * 32 + col] = v;
-    __syncthreads();
-    if (threadIdx.x < 32) {
-        float t = sums_lds[col];
-        for (int c = 1; c < 8; ++c) t += sums_lds[c * 32 + col];
-        sums_lds[col] = t;
-    }
-    __syncthreads();
-}
-
-__global__ __launch_bounds__(256) void k_sum_partials(float *sums, const float *partials, int nblocks) {
-    __shared__ float lds[8 * 32];
-    sum_partials_block(lds, partials, nblocks);
-    if (threadIdx.x < 32) sums[threadIdx.x] = lds[threadIdx.x];
-}
-
-hipError_t launch_sum_partials(float *sums, const float *partials, int nblocks, hipStream_t s) {
-    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, s, sums, partials, nblocks);
-    return hipGetLastError();
-}
-
-// =====================================================================================================
-// solve + updatePoseKernel + checkPoseKernel on the device (one lane, double precision).
-// The reference solves the 6x6 normal equations with an SVD back-substitution that zeroes singular
-// values below sigma_max / 1e6.  For a symmetric positive definite system whose condition number is
-// provably below 1e6 that is the plain solution, obtained here by Cholesky; otherwise the eigen
-// decomposition (cyclic Jacobi) applies the truncation rule literally.
-// =====================================================================================================
-__device__ void jacobi_solve6(const double C_in[6][6], const double b[6], double x[6]) {
-    double A[6][6], V[6][6];
-    for (int i = 0; i < 6; ++i)
-        for (int j = 0; j < 6; ++j) { A[i][j] = C_in[i][j]; V[i][j] = (i == j) ? 1.0 : 0.0; }
+// Slow path: cyclic Jacobi eigen-decomposition of the symmetric 6x6 matrix held one element per lane
+// (lane = 8*row + column, rows/columns 6 and 7 are zero padding), then the truncated pseudo-inverse
+// x = sum_i [ |w_i| * 1e6 > max|w| ] (v_i . b / w_i) v_i.  No per-lane arrays: every access to another
+// element is a cross-lane read, so the routine needs no scratch memory.
+__device__ void jacobi_solve6_wave(double a, const double b[6], double x[6]) {
+    const int lane = threadIdx.x & 63;
+    const int i = lane >> 3, j = lane & 7;
+    const bool in_c = i < 6 && j < 6;
+    double v = (i == j && i < 6) ? 1.0 : 0.0;
+#pragma unroll 1
     for (int sweep = 0; sweep < 64; ++sweep) {
-        double off = 0.0, diag = 0.0;
-        for (int i = 0; i < 6; ++i) {
-            diag += A[i][i] * A[i][i];
-            for (int j = i + 1; j < 6; ++j) off += A[i][j] * A[i][j];
-        }
+        const double off = wave_sum_f64((in_c && i < j) ? a * a : 0.0);
+        const double diag = wave_sum_f64((in_c && i == j) ? a * a : 0.0);
         if (off == 0.0 || off <= 1e-40 * diag) break;
-        for (int p = 0; p < 5; ++p)
+#pragma unroll 1
+        for (int p = 0; p < 5; ++p) {
+#pragma unroll 1
             for (int q = p + 1; q < 6; ++q) {
-                const double apq = A[p][q];
-                if (apq == 0.0) continue;
-                const double theta = (A[q][q] - A[p][p]) / (2.0 * apq);
+                const double apq = __shfl(a, p * 8 + q, 64);
+                if (apq == 0.0) continue;                              // wave-uniform
+                const double app = __shfl(a, p * 8 + p, 64), aqq = __shfl(a, q * 8 + q, 64);
+                const double theta = (aqq - app) / (2.0 * apq);
                 const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
                 const double c = 1.0 / sqrt(t * t + 1.0);
                 const double s = t * c;
-                for (int k = 0; k < 6; ++k) {
-                    const double akp = A[k][p], akq = A[k][q];
-                    A[k][p] = c * akp - s * akq;
-                    A[k][q] = s * akp + c * akq;
-                }
-                for (int k = 0; k < 6; ++k) {
-                    const double apk = A[p][k], aqk = A[q][k];
-                    A[p][k] = c * apk - s * aqk;
-                    A[q][k] = s * apk + c * aqk;
-                }
-                for (int k = 0; k < 6; ++k) {
-                    const double vkp = V[k][p], vkq = V[k][q];
-                    V[k][p] = c * vkp - s * vkq;
-                    V[k][q] = s * vkp + c * vkq;
-                }
+                // columns p and q of A
+                double aip = __shfl(a, i * 8 + p, 64), aiq = __shfl(a, i * 8 + q, 64);
+                if (j == p) a = c * aip - s * aiq;
+                else if (j == q) a = s * aip + c * aiq;
+                // rows p and q of A
+                const double apj = __shfl(a, p * 8 + j, 64), aqj = __shfl(a, q * 8 + j, 64);
+                if (i == p) a = c * apj - s * aqj;
+                else if (i == q) a = s * apj + c * aqj;
+                // columns p and q of V
+                const double vip = __shfl(v, i * 8 + p, 64), viq = __shfl(v, i * 8 + q, 64);
+                if (j == p) v = c * vip - s * viq;
+                else if (j == q) v = s * vip + c * viq;
             }
-    }
-    double wmax = 0.0;
-    for (int i = 0; i < 6; ++i) wmax = fmax(wmax, fabs(A[i][i]));
-    for (int i = 0; i < 6; ++i) x[i] = 0.0;
-    for (int i = 0; i < 6; ++i) {
-        const double w = A[i][i];
-        if (!(fabs(w) * 1e6 > wmax)) continue;
-        double p = 0.0;
-        for (int j = 0; j < 6; ++j) p += V[j][i] * b[j];
-        p /= w;
-        for (int j = 0; j < 6; ++j) x[j] += p * V[j][i];
-    }
-}
-
-// Returns true when the Cholesky solution is valid AND cond_2(C) < 1e6 is certain
-// (cond_2 <= trace(C) * ||L^-1||_F^2).
-__device__ bool cholesky_solve6(const double C[6][6], const double b[6], double x[6]) {
-    double L[6][6];
-    double trace = 0.0;
-    for (int i = 0; i < 6; ++i) trace += C[i][i];
-    for (int j = 0; j < 6; ++j) {
-        double d = C[j][j];
-        for (int k = 0; k < j; ++k) d -= L[j][k] * L[j][k];
-        if (!(d > 0.0)) return false;
-        const double ljj = sqrt(d);
-        L[j][j] = ljj;
-        const double inv = 1.0 / ljj;
-        for (int i = j + 1; i < 6; ++i) {
-            double s = C[i][j];
-            for (int k = 0; k < j; ++k) s -= L[i][k] * L[j][k];
-            L[i][j] = s * inv;
         }
     }
-    // M = L^-1 (lower triangular), accumulate its squared Frobenius norm
-    double M[6][6];
-    double fro2 = 0.0;
-    for (int j = 0; j < 6; ++j) {
-        M[j][j] = 1.0 / L[j][j];
-        fro2 += M[j][j] * M[j][j];
-        for (int i = j + 1; i < 6; ++i) {
-            double s = 0.0;
-            for (int k = j; k < i; ++k) s -= L[i][k] * M[k][j];
-            M[i][j] = s / L[i][i];
-            fro2 += M[i][j] * M[i][j];
-        }
-    }
-    if (!(trace * fro2 < 1e6)) return false;
-    // x = M^T (M b)
-    double y[6];
-    for (int i = 0; i < 6; ++i) {
-        double s = 0.0;
-        for (int k = 0; k <= i; ++k) s += M[i][k] * b[k];
-        y[i] = s;
-    }
-    for (int i = 0; i < 6; ++i) {
-        double s = 0.0;
-        for (int k = i; k < 6; ++k) s += M[k][i] * y[k];
-        x[i] = s;
-    }
-    return true;
+    // eigenvalue of column j, broadcast down the column
+    const double w = __shfl(a, j * 8 + j, 64);
+    double wmax = (in_c && i == j) ? fabs(a) : 0.0;
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) wmax = fmax(wmax, __shfl_xor(wmax, m, 64));
+    // p_j = sum_i V[i][j] * b[i]  (sum over rows: lanes that differ in bits 3..5)
+    double bi = 0.0;
+#pragma unroll
+    for (int m = 0; m < 6; ++m) bi = (i == m) ? b[m] : bi;
+    double pj = in_c ? v * bi : 0.0;
+    pj += __shfl_xor(pj, 8, 64);
+    pj += __shfl_xor(pj, 16, 64);
+    pj += __shfl_xor(pj, 32, 64);
+    const bool keep = in_c && (fabs(w) * 1e6 > wmax);
+    // x_i = sum_j keep_j * (p_j / w_j) * V[i][j]  (sum over columns: lanes that differ in bits 0..2)
+    double xi = keep ? (pj / w) * v : 0.0;
+    xi += __shfl_xor(xi, 1, 64);
+    xi += __shfl_xor(xi, 2, 64);
+    xi += __shfl_xor(xi, 4, 64);
+#pragma unroll
+    for (int m = 0; m < 6; ++m) x[m] = __shfl(xi, m * 8, 64);
 }
 
-__device__ void solve_normal_equations(const float *vals /*27*/, double x[6]) {
-    double b[6], C[6][6];
-    for (int i = 0; i < 6; ++i) b[i] = (double)vals[i];
-    int k = 6;
-    for (int i = 0; i < 6; ++i)
-        for (int j = i; j < 6; ++j) { C[i][j] = (double)vals[k]; C[j][i] = (double)vals[k]; ++k; }
-    if (!cholesky_solve6(C, b, x)) jacobi_solve6(C, b, x);
+// Called by all 64 lanes of one wavefront; vals = 27 floats {b[6], upper triangle of C}.  x is returned
+// in every lane.  *used_jacobi (may be null) reports which path produced it.
+__device__ void solve_normal_equations_wave(const float *vals, double x[6], int *used_jacobi) {
+    const int lane = threadIdx.x & 63;
+    const int i = lane >> 3, j = lane & 7;
+    double a = 0.0;
+    if (i < 6) {
+        if (j < 6) {
+            const int r = min(i, j), c = max(i, j);
+            a = (double)vals[6 + r * 6 - (r * (r - 1)) / 2 + (c - r)];
+        } else if (j == 6) {
+            a = (double)vals[i];
+        }
+    }
+    const bool in_c = i < 6 && j < 6;
+    const double c_elem = in_c ? a : 0.0;
+    double inv = (i == j && i < 6) ? 1.0 : 0.0;
+    const double fro_c2 = wave_sum_f64(c_elem * c_elem);
+    bool spd = true;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const double p = __shfl(a, k * 8 + k, 64);
+        if (!(p > 0.0)) spd = false;                 // wave-uniform
+        const double rinv = 1.0 / p;
+        const double rk_a = __shfl(a, k * 8 + j, 64) * rinv;
+        const double rk_i = __shfl(inv, k * 8 + j, 64) * rinv;
+        const double ck = __shfl(a, i * 8 + k, 64);
+        if (i == k) {
+            a = rk_a;
+            inv = rk_i;
+        } else {
+            a = a - ck * rk_a;
+            inv = inv - ck * rk_i;
+        }
+    }
+    const double fro_i2 = wave_sum_f64(in_c ? inv * inv : 0.0);
+    const bool certified = spd && (fro_c2 * fro_i2 < 1e12);   // (||C||_F ||C^-1||_F)^2 < (1e6)^2
+    if (certified) {
+#pragma unroll
+        for (int m = 0; m < 6; ++m) x[m] = __shfl(a, m * 8 + 6, 64);
+    } else {
+        double b[6];
+#pragma unroll
+        for (int m = 0; m < 6; ++m) b[m] = (double)vals[m];
+        jacobi_solve6_wave(c_elem, b, x);
+    }
+    if (used_jacobi) *used_jacobi = certified ? 0 : 1;
 }
 
 // SE(3) exponential of a twist (translation first, rotation last), double in, float 4x4 out.
@@ -474,9 +404,10 @@ __device__ Mat4 se3_exp(const double mu[6]) {
     return out;
 }
 
-// pose <- exp(x) * pose ; returns |x| < threshold
-__device__ bool update_pose_dev(Mat4 &pose, const float *sums, float icp_threshold, double x[6]) {
-    solve_normal_equations(sums + 1, x);
+// pose <- exp(x) * pose ; returns |x| < threshold.  Wave-cooperative: all 64 lanes call it and all get
+// the same pose, x and result.
+__device__ bool update_pose_wave(Mat4 &pose, const float *sums, float icp_threshold, double x[6], int *used_jacobi) {
+    solve_normal_equations_wave(sums + 1, x, used_jacobi);
     const Mat4 delta = se3_exp(x);
     pose = mat_mul(delta, pose);
     double n2 = 0.0;
@@ -484,7 +415,8 @@ __device__ bool update_pose_dev(Mat4 &pose, const float *sums, float icp_thresho
     return sqrt(n2) < (double)icp_threshold;
 }
 
-// Matrices the later phases of the frame (and the next frame's tracking) read.
+// Matrices the later phases of the frame (and the next frame's tracking) read, and the ICP state the next
+// frame's first iteration starts from.
 __device__ void derive_matrices(Ctrl *c, const float k[4], bool set_raycast_pose) {
     c->inv_pose = mat_inverse(c->pose);
     c->view = mat_mul(c->pose, inverse_camera_matrix(k[0], k[1], k[2], k[3]));
@@ -493,9 +425,18 @@ __device__ void derive_matrices(Ctrl *c, const float k[4], bool set_raycast_pose
         c->project_ref = mat_mul(camera_matrix(k[0], k[1], k[2], k[3]), mat_inverse(c->raycast_pose));
     }
     c->old_pose = c->pose;
+    IcpState *st = &c->icp[0];
+    st->pose = c->pose;
+    for (int i = 0; i < 32; ++i) st->sums[i] = c->sums[i];
+    st->pending_nblocks = 0;
+    st->pending_level = 0;
+    st->pending_last = 0;
+    st->done_mask = 0;
+    st->iterations = 0;
+    st->slow_solves = 0;
 }
 
-__device__ void finish_tracking(const SolveArgs &a, bool ran_tracking) {
+__device__ void finish_tracking(const FinishArgs &a, bool ran_tracking, int iterations, int slow_solves) {
     Ctrl *c = a.ctrl;
     int tracked = 0;
     if (ran_tracking) {
@@ -521,52 +462,279 @@ __device__ void finish_tracking(const SolveArgs &a, bool ran_tracking) {
         st->raycasted = a.will_raycast;
         for (int i = 0; i < 16; ++i) st->pose[i] = c->pose.m[i];
         for (int i = 0; i < 32; ++i) st->sums[i] = c->sums[i];
+        st->icp_iterations = iterations;
+        st->slow_solves = slow_solves;
     }
 }
 
-__global__ __launch_bounds__(256) void k_icp_solve(SolveArgs a) {
-    Ctrl *c = a.ctrl;
-    if (c->level_done[a.level] == a.frame + 1) return;   // uniform: every thread reads the same word
-    __shared__ float lds[8 * 32];
-    sum_partials_block(lds, a.partials, a.nblocks);
-    if (threadIdx.x == 0) {
-        for (int i = 0; i < 32; ++i) c->sums[i] = lds[i];
-        Mat4 pose = c->pose;
-        double x[6];
-        const bool converged = update_pose_dev(pose, lds, a.icp_threshold, x);
-        c->pose = pose;
-        for (int i = 0; i < 6; ++i) c->x[i] = x[i];
-        const bool level_finished = converged || a.last_iter_of_level;
-        if (level_finished) {
-            c->level_done[a.level] = a.frame + 1;
-            if (a.final_level) finish_tracking(a, true);
+// =====================================================================================================
+// One ICP iteration = one launch.  Every block first finalises the PREVIOUS iteration (fixed-order sum of
+// its partial rows, 6x6 solve, pose update, convergence test) and then evaluates this iteration's residuals
+// with the new pose.  All blocks compute the same pose from the same data, so no block waits for another
+// and an iteration costs one kernel boundary instead of two.  The state travels through two alternating
+// IcpState records and two alternating partial-row buffers: launch `seq` reads record seq & 1 and row
+// buffer seq & 1, and block 0 writes record (seq + 1) & 1.
+//
+// trackKernel + reduceKernel: all input loads are issued before the prologue and all reference gathers
+// before the residuals; the residual is evaluated branch-free so the gathers stay unconditional.  The 32
+// sums stay in registers; a DPP wavefront reduction and an LDS stage across the block's waves produce one
+// 32-float partial row per block.  Row layout: [0] sum e^2, [1..6] sum e*J, [7..27] upper triangle of
+// sum J J^T, [28] valid, [29] result==-4, [30] result==-5, [31] result in {-1,-2,-3}.
+// Algorithmic bytes: 64 B per pixel (in vertex+normal, gathered reference vertex+normal) + 128 B per block.
+// =====================================================================================================
+struct IcpShared {
+    float red[KFH_TRACK_THREADS];   // partial-row chains, then the sums in red[0..31]
+    Mat4 pose;
+    int done_mask, iterations, slow_solves;
+};
+
+// Called by every thread of a KFH_TRACK_THREADS block.  Leaves pose / sums / counters after the pending
+// iteration (if any) in `sh`.
+__device__ inline void icp_finalize_pending(const IcpState *__restrict__ in, const float *__restrict__ partials_in,
+                                            float icp_threshold, IcpShared &sh) {
+    const int pend = in->pending_nblocks;            // uniform
+    if (pend > 0) {
+        sum_partials_block<KFH_TRACK_THREADS>(sh.red, partials_in, pend);
+        if (threadIdx.x < 64) {                      // the solve runs on wavefront 0
+            Mat4 pose = in->pose;
+            double x[6];
+            int slow;
+            const bool converged = update_pose_wave(pose, sh.red, icp_threshold, x, &slow);
+            if (threadIdx.x == 0) {
+                sh.pose = pose;
+                const bool level_finished = converged || in->pending_last != 0;
+                sh.done_mask = in->done_mask | (level_finished ? (1 << in->pending_level) : 0);
+                sh.iterations = in->iterations + 1;
+                sh.slow_solves = in->slow_solves + slow;
+            }
+        }
+    } else {
+        if (threadIdx.x < 32) sh.red[threadIdx.x] = in->sums[threadIdx.x];
+        if (threadIdx.x == 0) {
+            sh.pose = in->pose;
+            sh.done_mask = in->done_mask;
+            sh.iterations = in->iterations;
+            sh.slow_solves = in->slow_solves;
         }
     }
+    __syncthreads();
 }
 
-hipError_t launch_icp_solve(const SolveArgs &a, hipStream_t s) {
-    hipLaunchKernelGGL(k_icp_solve, dim3(1), dim3(256), 0, s, a);
+__device__ inline void icp_store_state(IcpState *out, const IcpShared &sh, int pending_nblocks, int level,
+                                       int last_iter) {
+    // one wavefront of block 0: lanes 0..31 store the sums, lane 0 the rest
+    if (threadIdx.x < 32) out->sums[threadIdx.x] = sh.red[threadIdx.x];
+    if (threadIdx.x == 0) {
+        out->pose = sh.pose;
+        out->pending_nblocks = pending_nblocks;
+        out->pending_level = level;
+        out->pending_last = last_iter;
+        out->done_mask = sh.done_mask;
+        out->iterations = sh.iterations;
+        out->slow_solves = sh.slow_solves;
+    }
+}
+
+__global__ __launch_bounds__(KFH_TRACK_THREADS) void k_icp_iteration(IcpIterArgs a) {
+    constexpr int PPT = KFH_TRACK_PIX_PER_THREAD;
+    __shared__ IcpShared sh;
+    const int npix = a.iw * a.ih;
+    const int base = blockIdx.x * (KFH_TRACK_THREADS * PPT) + threadIdx.x;
+
+    // this iteration's input pixels: in flight while the previous iteration is finalised
+    float4 nin4[PPT], vin4[PPT];
+    bool live[PPT];
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+        const int p = base + k * KFH_TRACK_THREADS;
+        live[k] = p < npix;
+        const int pc = live[k] ? p : 0;
+        nin4[k] = a.in_normal[pc];
+        vin4[k] = a.in_vertex[pc];
+    }
+
+    const IcpState *in = &a.ctrl->icp[a.seq & 1];
+    IcpState *out = &a.ctrl->icp[(a.seq + 1) & 1];
+    icp_finalize_pending(in, a.partials_in, a.icp_threshold, sh);
+
+    if (sh.done_mask & (1 << a.level)) {             // this level already finished: nothing to evaluate
+        if (blockIdx.x == 0) icp_store_state(out, sh, 0, a.level, 0);
+        return;
+    }
+
+    Mat4 Ttrack;
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+        Ttrack.m[i] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, sh.pose.m[i])));
+    const Mat4 view = a.ctrl->project_ref;
+
+    f3 projectedVertex[PPT];
+    bool img_ok[PPT];
+    unsigned ridx[PPT];
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+        projectedVertex[k] = xform(Ttrack, mk3(vin4[k].x, vin4[k].y, vin4[k].z));
+        const f3 projectedPos = xform(view, projectedVertex[k]);
+        const float px = projectedPos.x / projectedPos.z + 0.5f;
+        const float py = projectedPos.y / projectedPos.z + 0.5f;
+        img_ok[k] = !(px < 0 || px > a.rw - 1 || py < 0 || py > a.rh - 1);
+        const bool fetch = img_ok[k] && nin4[k].x != KFH_INVALID;
+        ridx[k] = fetch ? (unsigned)px + (unsigned)py * (unsigned)a.rw : 0u;
+    }
+    float4 rn4[PPT], rv4[PPT];
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+        rn4[k] = a.ref_normal[ridx[k]];
+        rv4[k] = a.ref_vertex[ridx[k]];
+    }
+
+    float acc[32];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) acc[i] = 0.0f;
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+        const f3 referenceNormal = mk3(rn4[k].x, rn4[k].y, rn4[k].z);
+        const f3 diff = mk3(rv4[k].x, rv4[k].y, rv4[k].z) - projectedVertex[k];
+        const f3 projectedNormal = rotate(Ttrack, mk3(nin4[k].x, nin4[k].y, nin4[k].z));
+        const bool dist_bad = length3(diff) > a.dist_threshold;
+        const bool normal_bad = dot3(projectedNormal, referenceNormal) < a.normal_threshold;
+        const int result = nin4[k].x == KFH_INVALID ? -1
+                           : !img_ok[k]            ? -2
+                           : rn4[k].x == KFH_INVALID ? -3
+                           : dist_bad              ? -4
+                           : normal_bad            ? -5
+                                                   : 1;
+        const bool valid = result == 1;
+        const f3 c = cross3(projectedVertex[k], referenceNormal);
+        const float error = valid ? dot3(referenceNormal, diff) : 0.f;
+        float J[6];
+        J[0] = valid ? referenceNormal.x : 0.f; J[1] = valid ? referenceNormal.y : 0.f;
+        J[2] = valid ? referenceNormal.z : 0.f;
+        J[3] = valid ? c.x : 0.f; J[4] = valid ? c.y : 0.f; J[5] = valid ? c.z : 0.f;
+        if (a.track_out && live[k]) {
+            const int p = base + k * KFH_TRACK_THREADS;
+            const int y = p / a.iw, x = p - y * a.iw;
+            kfh_track_data td;
+            td.result = result;
+            td.error = error;
+            for (int i = 0; i < 6; ++i) td.J[i] = J[i];
+            a.track_out[x + y * a.track_stride] = td;
+        }
+        const bool count = live[k];
+        acc[0] += (count ? error : 0.f) * error;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) acc[1 + i] += (count ? error : 0.f) * J[i];
+        int q = 7;
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+            for (int j = i; j < 6; ++j) acc[q++] += (count ? J[i] : 0.f) * J[j];
+        acc[28] += (count && valid) ? 1.f : 0.f;
+        acc[29] += (count && result == -4) ? 1.f : 0.f;
+        acc[30] += (count && result == -5) ? 1.f : 0.f;
+        acc[31] += (count && result < 1 && result > -4) ? 1.f : 0.f;
+    }
+
+    constexpr int NWAVES = KFH_TRACK_THREADS / 64;
+    __shared__ float wsum[NWAVES][32];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+        const float v = wave_sum_to_lane63(acc[i]);
+        if (lane == 63) wsum[wave][i] = v;
+    }
+    if (blockIdx.x == 0) icp_store_state(out, sh, gridDim.x, a.level, a.last_iter);
+    __syncthreads();
+    if (threadIdx.x < 32) {
+        float v = wsum[0][threadIdx.x];
+#pragma unroll
+        for (int wv = 1; wv < NWAVES; ++wv) v += wsum[wv][threadIdx.x];
+        a.partials_out[blockIdx.x * 32 + threadIdx.x] = v;
+    }
+}
+
+hipError_t launch_icp_iteration(const IcpIterArgs &a, hipStream_t s) {
+    const int nb = track_blocks(a.iw, a.ih);
+    hipLaunchKernelGGL(k_icp_iteration, dim3(nb), dim3(KFH_TRACK_THREADS), 0, s, a);
     return hipGetLastError();
 }
 
-__global__ void k_track_skip(SolveArgs a) {
-    if (threadIdx.x == 0) finish_tracking(a, false);
+// Last launch of tracking: finalise the last iteration, then checkPoseKernel and the derived matrices.
+__global__ __launch_bounds__(KFH_TRACK_THREADS) void k_icp_finish(FinishArgs a) {
+    __shared__ IcpShared sh;
+    Ctrl *c = a.ctrl;
+    icp_finalize_pending(&c->icp[a.seq & 1], a.partials_in, a.icp_threshold, sh);
+    if (threadIdx.x == 0) {
+        c->pose = sh.pose;
+        for (int i = 0; i < 32; ++i) c->sums[i] = sh.red[i];
+        finish_tracking(a, true, sh.iterations, sh.slow_solves);
+    }
 }
 
-hipError_t launch_track_skip(const SolveArgs &a, hipStream_t s) {
+hipError_t launch_icp_finish(const FinishArgs &a, hipStream_t s) {
+    hipLaunchKernelGGL(k_icp_finish, dim3(1), dim3(KFH_TRACK_THREADS), 0, s, a);
+    return hipGetLastError();
+}
+
+__global__ void k_track_skip(FinishArgs a) {
+    if (threadIdx.x == 0) finish_tracking(a, false, 0, 0);
+}
+
+hipError_t launch_track_skip(const FinishArgs &a, hipStream_t s) {
     hipLaunchKernelGGL(k_track_skip, dim3(1), dim3(64), 0, s, a);
     return hipGetLastError();
 }
 
-__global__ void k_update_pose(float *pose16, double *x6, int *converged, const float *sums, float thr) {
+// trackKernel + reduceKernel on caller-provided matrices (parity tests): one iteration launch whose state
+// record carries Ttrack, then the fixed-order sum of its partial rows.
+__global__ void k_icp_seed(Ctrl *c, Mat4 Ttrack, Mat4 view) {
     if (threadIdx.x != 0) return;
+    c->project_ref = view;
+    IcpState *st = &c->icp[0];
+    st->pose = Ttrack;
+    for (int i = 0; i < 32; ++i) st->sums[i] = 0.f;
+    st->pending_nblocks = 0;
+    st->pending_level = 0;
+    st->pending_last = 0;
+    st->done_mask = 0;
+    st->iterations = 0;
+    st->slow_solves = 0;
+}
+
+hipError_t launch_track_reduce(Ctrl *scratch_ctrl, float *partials, float *sums, kfh_track_data *track_out,
+                               int track_stride, const float4 *in_vertex, const float4 *in_normal, int iw, int ih,
+                               const float4 *ref_vertex, const float4 *ref_normal, int rw, int rh,
+                               const Mat4 &Ttrack, const Mat4 &view, float dist_threshold, float normal_threshold,
+                               hipStream_t s) {
+    hipLaunchKernelGGL(k_icp_seed, dim3(1), dim3(64), 0, s, scratch_ctrl, Ttrack, view);
+    IcpIterArgs a;
+    a.ctrl = scratch_ctrl;
+    a.partials_in = partials;
+    a.partials_out = partials;
+    a.seq = 0;
+    a.level = 0;
+    a.last_iter = 1;
+    a.in_vertex = in_vertex; a.in_normal = in_normal; a.iw = iw; a.ih = ih;
+    a.ref_vertex = ref_vertex; a.ref_normal = ref_normal; a.rw = rw; a.rh = rh;
+    a.dist_threshold = dist_threshold; a.normal_threshold = normal_threshold;
+    a.icp_threshold = 0.f;
+    a.track_out = track_out; a.track_stride = track_stride;
+    hipError_t e = launch_icp_iteration(a, s);
+    if (e != hipSuccess) return e;
+    return launch_sum_partials(sums, partials, track_blocks(iw, ih), s);
+}
+
+__global__ void k_update_pose(float *pose16, double *x6, int *converged, const float *sums, float thr) {
     Mat4 pose;
     for (int i = 0; i < 16; ++i) pose.m[i] = pose16[i];
     double x[6];
-    const bool conv = update_pose_dev(pose, sums, thr, x);
+    int used_jacobi;
+    const bool conv = update_pose_wave(pose, sums, thr, x, &used_jacobi);
+    if (threadIdx.x != 0) return;
     for (int i = 0; i < 16; ++i) pose16[i] = pose.m[i];
     for (int i = 0; i < 6; ++i) x6[i] = x[i];
-    *converged = conv ? 1 : 0;
+    converged[0] = conv ? 1 : 0;
+    converged[1] = used_jacobi;
 }
 
 hipError_t launch_update_pose(float *pose16, double *x6, int *converged, const float *sums, float thr,
@@ -594,15 +762,21 @@ hipError_t launch_pose_derive(Ctrl *ctrl, const float k[4], int set_raycast_pose
 // A slab [z0, z1) replays the z < z0 additions without touching memory; `vol` starts at plane z0.
 // Algorithmic bytes (convention): 8 B per voxel (4 read + 4 written) x voxels of the slab.
 // =====================================================================================================
+constexpr int INTEGRATE_UNROLL = 8;
+
 __global__ __launch_bounds__(256) void k_integrate(short2 *__restrict__ vol, int sx, int sy, int sz,
                                                    float dimx, float dimy, float dimz, int z0, int z1,
                                                    const float *__restrict__ depth, int w, int h,
                                                    const Mat4 *__restrict__ inv_track_p, Mat4 K, float mu,
-                                                   float maxweight, const int *__restrict__ gate) {
+                                                   float maxweight, const int *__restrict__ gate, int zchunk) {
     if (gate && *gate == 0) return;
     const int x = blockIdx.x * 64 + (threadIdx.x & 63);
     const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= sx || y >= sy) return;
+    // blockIdx.z selects a z chunk of the column; the steps below it are replayed arithmetically
+    const int zc0 = max(z0, (int)blockIdx.z * zchunk);
+    const int zc1 = min(z1, ((int)blockIdx.z + 1) * zchunk);
+    if (zc0 >= zc1) return;
     const Mat4 invTrack = *inv_track_p;
     const f3 delta = rotate(invTrack, mk3(0, 0, dimz / (float)sz));
     const f3 cameraDelta = rotate(K, delta);
@@ -613,26 +787,65 @@ __global__ __launch_bounds__(256) void k_integrate(short2 *__restrict__ vol, int
     const float wmax = (float)(w - 1), hmax = (float)(h - 1);
     const size_t plane = (size_t)sx * sy;
     short2 *col = vol + (size_t)x + (size_t)y * sx;
-    for (int z = 0; z < z1; ++z, pos = pos + delta, cameraX = cameraX + cameraDelta) {
-        if (z < z0) continue;
-        if (pos.z < 0.0001f) continue;
-        const float pxf = cameraX.x / cameraX.z + 0.5f;
-        const float pyf = cameraX.y / cameraX.z + 0.5f;
-        if (pxf < 0 || pxf > wmax || pyf < 0 || pyf > hmax) continue;
-        const unsigned px = (unsigned)pxf, py = (unsigned)pyf;
-        const float d = depth[px + py * w];
-        if (d == 0) continue;
-        const float rx = pos.x / pos.z, ry = pos.y / pos.z;
-        const float diff = (d - cameraX.z) * sqrtf(1 + rx * rx + ry * ry);
-        if (diff > -mu) {
-            const float sdf = fminf(1.f, diff / mu);
-            short2 *v = col + (size_t)(z - z0) * plane;
-            const short2 raw = *v;
-            float tsdf = (float)raw.x * KFH_SHORT2FLOAT;
-            float wgt = (float)raw.y;
-            tsdf = fmaxf(-1.f, fminf((wgt * tsdf + sdf) / (wgt + 1), 1.f));
-            wgt = fminf(wgt + 1, maxweight);
-            *v = make_short2((short)(tsdf * KFH_FLOAT2SHORT), (short)wgt);
+    // INTEGRATE_UNROLL z steps are advanced arithmetically, then their depth pixels and voxels are fetched
+    // together (the voxel read is issued as soon as the pixel test passes, before the depth value is
+    // known) and finally updated: one memory round trip per group instead of two per voxel.
+    for (int z = 0; z < zc0; ++z) {
+        pos = pos + delta;
+        cameraX = cameraX + cameraDelta;
+    }
+    for (int zb = zc0; zb < zc1; zb += INTEGRATE_UNROLL) {
+        f3 posk[INTEGRATE_UNROLL];
+        float camz[INTEGRATE_UNROLL];
+        unsigned pidx[INTEGRATE_UNROLL];
+        bool cand[INTEGRATE_UNROLL];
+#pragma unroll
+        for (int u = 0; u < INTEGRATE_UNROLL; ++u) {
+            const int z = zb + u;
+            posk[u] = pos;
+            camz[u] = cameraX.z;
+            bool c = z < zc1 && !(pos.z < 0.0001f);
+            // Cheap conservative rejection (one pixel of slack, far above the rounding of the exact test):
+            // a voxel that fails it cannot pass the exact in-image test below.
+            if (c && (cameraX.x < -1.5f * cameraX.z || cameraX.x > (wmax + 1.5f) * cameraX.z ||
+                      cameraX.y < -1.5f * cameraX.z || cameraX.y > (hmax + 1.5f) * cameraX.z))
+                c = false;
+            unsigned pi = 0;
+            if (c) {
+                const float pxf = cameraX.x / cameraX.z + 0.5f;
+                const float pyf = cameraX.y / cameraX.z + 0.5f;
+                if (pxf < 0 || pxf > wmax || pyf < 0 || pyf > hmax) c = false;
+                else pi = (unsigned)pxf + (unsigned)pyf * (unsigned)w;
+            }
+            cand[u] = c;
+            pidx[u] = pi;
+            pos = pos + delta;
+            cameraX = cameraX + cameraDelta;
+        }
+        float dk[INTEGRATE_UNROLL];
+        short2 rawk[INTEGRATE_UNROLL];
+#pragma unroll
+        for (int u = 0; u < INTEGRATE_UNROLL; ++u) {
+            dk[u] = 0.f;
+            rawk[u] = make_short2(0, 0);
+            if (cand[u]) {
+                dk[u] = depth[pidx[u]];
+                rawk[u] = col[(size_t)(zb + u - z0) * plane];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < INTEGRATE_UNROLL; ++u) {
+            if (!cand[u] || dk[u] == 0) continue;
+            const float rx = posk[u].x / posk[u].z, ry = posk[u].y / posk[u].z;
+            const float diff = (dk[u] - camz[u]) * sqrtf(1 + rx * rx + ry * ry);
+            if (diff > -mu) {
+                const float sdf = fminf(1.f, diff / mu);
+                float tsdf = (float)rawk[u].x * KFH_SHORT2FLOAT;
+                float wgt = (float)rawk[u].y;
+                tsdf = fmaxf(-1.f, fminf((wgt * tsdf + sdf) / (wgt + 1), 1.f));
+                wgt = fminf(wgt + 1, maxweight);
+                col[(size_t)(zb + u - z0) * plane] = make_short2((short)(tsdf * KFH_FLOAT2SHORT), (short)wgt);
+            }
         }
     }
 }
@@ -640,9 +853,17 @@ __global__ __launch_bounds__(256) void k_integrate(short2 *__restrict__ vol, int
 hipError_t launch_integrate(short2 *vol, const int res[3], const float dim[3], int z0, int z1,
                             const float *depth, int w, int h, const Mat4 *inv_track, Mat4 K, float mu,
                             float maxweight, const int *gate, hipStream_t s) {
-    const dim3 grid((res[0] + 63) / 64, (res[1] + 3) / 4);
+    // enough z chunks to keep about eight wavefronts per SIMD resident (1024 SIMDs), each chunk a multiple
+    // of the unroll factor
+    const int gx = (res[0] + 63) / 64, gy = (res[1] + 3) / 4;
+    int split = 8192 / (gx * gy * 4);
+    split = split < 1 ? 1 : (split > 16 ? 16 : split);
+    int zchunk = (z1 + split - 1) / split;
+    zchunk = ((zchunk + INTEGRATE_UNROLL - 1) / INTEGRATE_UNROLL) * INTEGRATE_UNROLL;
+    const int gz = (z1 + zchunk - 1) / zchunk;
+    const dim3 grid(gx, gy, gz);
     hipLaunchKernelGGL(k_integrate, grid, dim3(256), 0, s, vol, res[0], res[1], res[2], dim[0], dim[1], dim[2],
-                       z0, z1, depth, w, h, inv_track, K, mu, maxweight, gate);
+                       z0, z1, depth, w, h, inv_track, K, mu, maxweight, gate, zchunk);
     return hipGetLastError();
 }
 
@@ -666,31 +887,94 @@ hipError_t launch_fill_volume(short2 *vol, size_t nvox, hipStream_t s) {
 // and holds planes [zs0, zs1); the march is clipped to z in [zc0, zc1] metres (the whole volume, or the
 // owned slab in the sharded mode).
 // =====================================================================================================
+constexpr int RAY_BATCH = 4;
+
+// Two x-adjacent voxels fetched with one 8-byte load (the volume is only 4-byte aligned at odd x).
+// The empty asm makes the whole 64-bit value live, so the load is not narrowed into two 2-byte loads.
+typedef unsigned long long u64_align4 __attribute__((aligned(4)));
+template <bool POW2>
 struct VolDev {
     const short2 *data;
     int sx, sy, sz;
     float dx, dy, dz;
-    int zs0, zs1;   // stored planes
-    __device__ inline float vs(int x, int y, int z) const {
-        z = min(max(z, zs0), zs1 - 1) - zs0;
-        return (float)data[(size_t)x + (size_t)y * sx + (size_t)z * sx * sy].x;
+    int zs0, zs1;        // stored planes
+    // size / dim; used when POW2 (sizes and dims are powers of two), where pos * size / dim == pos * (size / dim)
+    // bit for bit because both scalings are exact
+    float scx, scy, scz;
+
+    __device__ inline f3 to_voxel(f3 pos) const {
+        if (POW2) return mk3(pos.x * scx - 0.5f, pos.y * scy - 0.5f, pos.z * scz - 0.5f);
+        return mk3((pos.x * (float)sx / dx) - 0.5f, (pos.y * (float)sy / dy) - 0.5f,
+                   (pos.z * (float)sz / dz) - 0.5f);
     }
-    __device__ inline float interp(f3 pos) const {
-        const f3 sp = mk3((pos.x * (float)sx / dx) - 0.5f, (pos.y * (float)sy / dy) - 0.5f,
-                          (pos.z * (float)sz / dz) - 0.5f);
+    __device__ inline unsigned row(int y) const { return (unsigned)y * (unsigned)sx; }
+    __device__ inline unsigned plane(int z) const {
+        z = min(max(z, zs0), zs1 - 1) - zs0;
+        return (unsigned)z * (unsigned)(sx * sy);
+    }
+    __device__ inline float vs(int x, int y, int z) const {
+        return (float)data[(unsigned)x + row(y) + plane(z)].x;
+    }
+    // Trilinear sample of the raw tsdf shorts in three steps, so that a caller can put the fetches of
+    // several samples in flight before it consumes any of them.  lx and ux are either equal or adjacent,
+    // so each of the four (y, z) rows needs one 8-byte fetch at x0 = min(lx, sx - 2).
+    struct Tap {
+        unsigned o00, o10, o01, o11;   // voxel offsets of the four rows at x0
+        f3 f;                          // interpolation fractions
+        bool l_second, u_second;       // lower / upper x tap is the second voxel of the pair
+    };
+    struct TapData { unsigned long long r00, r10, r01, r11; };
+
+    __device__ inline Tap prep(f3 pos) const {
+        const f3 sp = to_voxel(pos);
         const float flx = floorf(sp.x), fly = floorf(sp.y), flz = floorf(sp.z);
         const int bx = (int)flx, by = (int)fly, bz = (int)flz;
-        const f3 f = mk3(sp.x - flx, sp.y - fly, sp.z - flz);
+        Tap t;
+        t.f = mk3(sp.x - flx, sp.y - fly, sp.z - flz);
         const int lx = max(bx, 0), ly = max(by, 0), lz = max(bz, 0);
         const int ux = min(bx + 1, sx - 1), uy = min(by + 1, sy - 1), uz = min(bz + 1, sz - 1);
-        return (((vs(lx, ly, lz) * (1 - f.x) + vs(ux, ly, lz) * f.x) * (1 - f.y) +
-                 (vs(lx, uy, lz) * (1 - f.x) + vs(ux, uy, lz) * f.x) * f.y) * (1 - f.z) +
-                ((vs(lx, ly, uz) * (1 - f.x) + vs(ux, ly, uz) * f.x) * (1 - f.y) +
-                 (vs(lx, uy, uz) * (1 - f.x) + vs(ux, uy, uz) * f.x) * f.y) * f.z) * KFH_SHORT2FLOAT;
+        const int x0 = min(lx, sx - 2);
+        t.l_second = lx != x0;
+        t.u_second = ux != x0;
+        const unsigned rl = row(ly), ru = row(uy), pl = plane(lz), pu = plane(uz);
+        t.o00 = (unsigned)x0 + rl + pl;
+        t.o10 = (unsigned)x0 + ru + pl;
+        t.o01 = (unsigned)x0 + rl + pu;
+        t.o11 = (unsigned)x0 + ru + pu;
+        return t;
+    }
+    __device__ inline TapData fetch(const Tap &t) const {
+        TapData d;
+        d.r00 = *reinterpret_cast<const u64_align4 *>(data + t.o00);
+        d.r10 = *reinterpret_cast<const u64_align4 *>(data + t.o10);
+        d.r01 = *reinterpret_cast<const u64_align4 *>(data + t.o01);
+        d.r11 = *reinterpret_cast<const u64_align4 *>(data + t.o11);
+        return d;
+    }
+    __device__ static inline float tap_first(unsigned long long r) { return (float)(short)(r & 0xFFFFull); }
+    __device__ static inline float tap_second(unsigned long long r) { return (float)(short)((r >> 32) & 0xFFFFull); }
+    __device__ inline float combine(const Tap &t, TapData d) const {
+        // the empty asm keeps each 64-bit value whole, so the loads are not narrowed to two 2-byte loads
+        asm("" : "+v"(d.r00), "+v"(d.r10), "+v"(d.r01), "+v"(d.r11));
+        const f3 f = t.f;
+        const float v000 = t.l_second ? tap_second(d.r00) : tap_first(d.r00);
+        const float v100 = t.u_second ? tap_second(d.r00) : tap_first(d.r00);
+        const float v010 = t.l_second ? tap_second(d.r10) : tap_first(d.r10);
+        const float v110 = t.u_second ? tap_second(d.r10) : tap_first(d.r10);
+        const float v001 = t.l_second ? tap_second(d.r01) : tap_first(d.r01);
+        const float v101 = t.u_second ? tap_second(d.r01) : tap_first(d.r01);
+        const float v011 = t.l_second ? tap_second(d.r11) : tap_first(d.r11);
+        const float v111 = t.u_second ? tap_second(d.r11) : tap_first(d.r11);
+        return (((v000 * (1 - f.x) + v100 * f.x) * (1 - f.y) + (v010 * (1 - f.x) + v110 * f.x) * f.y) * (1 - f.z) +
+                ((v001 * (1 - f.x) + v101 * f.x) * (1 - f.y) + (v011 * (1 - f.x) + v111 * f.x) * f.y) * f.z) *
+               KFH_SHORT2FLOAT;
+    }
+    __device__ inline float interp(f3 pos) const {
+        const Tap t = prep(pos);
+        return combine(t, fetch(t));
     }
     __device__ inline f3 grad(f3 pos) const {
-        const f3 sp = mk3((pos.x * (float)sx / dx) - 0.5f, (pos.y * (float)sy / dy) - 0.5f,
-                          (pos.z * (float)sz / dz) - 0.5f);
+        const f3 sp = to_voxel(pos);
         const float flx = floorf(sp.x), fly = floorf(sp.y), flz = floorf(sp.z);
         const int bx = (int)flx, by = (int)fly, bz = (int)flz;
         const f3 f = mk3(sp.x - flx, sp.y - fly, sp.z - flz);
@@ -729,8 +1013,9 @@ struct VolDev {
     }
 };
 
+template <bool POW2>
 __global__ __launch_bounds__(256) void k_raycast(float4 *__restrict__ vertex, float4 *__restrict__ normal,
-                                                 float *__restrict__ ray_t, int w, int h, VolDev vol,
+                                                 float *__restrict__ ray_t, int w, int h, VolDev<POW2> vol,
                                                  float zc0, float zc1, const Mat4 *__restrict__ view_p,
                                                  float near_plane, float far_plane, float step,
                                                  float largestep) {
@@ -762,11 +1047,44 @@ __global__ __launch_bounds__(256) void k_raycast(float4 *__restrict__ vertex, fl
         float f_t = vol.interp(origin + direction * t);
         float f_tt = 0;
         if (f_t > 0) {
-            for (; t < tfar; t += stepsize) {
-                f_tt = vol.interp(origin + direction * t);
-                if (f_tt < 0) break;
-                if (f_tt < 0.8f) stepsize = step;
-                f_t = f_tt;
+            // The reference loop is  for (; t < tfar; t += stepsize) { f_tt = interp(t); if (f_tt < 0) break;
+            // if (f_tt < 0.8) stepsize = step; f_t = f_tt; }.  The samples of RAY_BATCH consecutive steps are
+            // fetched together (their positions only depend on the current step size) and then consumed in
+            // order; a step-size change discards the rest of the batch.  Same samples, same decisions, one
+            // memory round trip per batch instead of one per step.
+            bool marching = t < tfar;
+            while (marching) {
+                float tk[RAY_BATCH], fk[RAY_BATCH];
+                tk[0] = t;
+#pragma unroll
+                for (int k = 1; k < RAY_BATCH; ++k) tk[k] = tk[k - 1] + stepsize;
+                typename VolDev<POW2>::Tap taps[RAY_BATCH];
+                typename VolDev<POW2>::TapData raw[RAY_BATCH];
+#pragma unroll
+                for (int k = 0; k < RAY_BATCH; ++k) {
+                    const float ts = tk[k] < tfar ? tk[k] : t;      // never sample past the far bound
+                    taps[k] = vol.prep(origin + direction * ts);
+                }
+#pragma unroll
+                for (int k = 0; k < RAY_BATCH; ++k) raw[k] = vol.fetch(taps[k]);
+#pragma unroll
+                for (int k = 0; k < RAY_BATCH; ++k) fk[k] = vol.combine(taps[k], raw[k]);
+                bool restart = false;
+#pragma unroll
+                for (int k = 0; k < RAY_BATCH; ++k) {
+                    if (!marching || restart) continue;
+                    if (!(tk[k] < tfar)) { t = tk[k]; marching = false; continue; }
+                    f_tt = fk[k];
+                    t = tk[k];
+                    if (f_tt < 0) { marching = false; continue; }
+                    f_t = f_tt;
+                    if (f_tt < 0.8f && stepsize != step) {
+                        stepsize = step;
+                        t = tk[k] + stepsize;
+                        restart = true;
+                    }
+                }
+                if (marching && !restart) t = tk[RAY_BATCH - 1] + stepsize;
             }
             if (f_tt < 0) {
                 t = t + stepsize * f_tt / (f_t - f_tt);
@@ -792,13 +1110,16 @@ __global__ __launch_bounds__(256) void k_raycast(float4 *__restrict__ vertex, fl
     if (ray_t) ray_t[o] = hit.w;
 }
 
-hipError_t launch_raycast(float4 *vertex, float4 *normal, float *ray_t, int w, int h, const short2 *vol,
-                          const int res[3], const float dim[3], int z0, int z1, const Mat4 *view,
-                          float near_plane, float far_plane, float step, float largestep, hipStream_t s) {
-    VolDev v;
+template <bool POW2>
+static hipError_t launch_raycast_t(float4 *vertex, float4 *normal, float *ray_t, int w, int h, const short2 *vol,
+                                   const int res[3], const float dim[3], int z0, int z1, const Mat4 *view,
+                                   float near_plane, float far_plane, float step, float largestep,
+                                   hipStream_t s) {
+    VolDev<POW2> v;
     v.data = vol;
     v.sx = res[0]; v.sy = res[1]; v.sz = res[2];
     v.dx = dim[0]; v.dy = dim[1]; v.dz = dim[2];
+    v.scx = (float)res[0] / dim[0]; v.scy = (float)res[1] / dim[1]; v.scz = (float)res[2] / dim[2];
     float zc0 = 0.f, zc1 = dim[2];
     if (z0 == 0 && z1 == res[2]) {
         v.zs0 = 0; v.zs1 = res[2];
@@ -810,9 +1131,25 @@ hipError_t launch_raycast(float4 *vertex, float4 *normal, float *ray_t, int w, i
         zc1 = (float)z1 * (dim[2] / (float)res[2]);
     }
     const dim3 grid((w + 15) / 16, (h + 15) / 16);
-    hipLaunchKernelGGL(k_raycast, grid, dim3(256), 0, s, vertex, normal, ray_t, w, h, v, zc0, zc1, view,
+    hipLaunchKernelGGL(k_raycast<POW2>, grid, dim3(256), 0, s, vertex, normal, ray_t, w, h, v, zc0, zc1, view,
                        near_plane, far_plane, step, largestep);
     return hipGetLastError();
+}
+
+hipError_t launch_raycast(float4 *vertex, float4 *normal, float *ray_t, int w, int h, const short2 *vol,
+                          const int res[3], const float dim[3], int z0, int z1, const Mat4 *view,
+                          float near_plane, float far_plane, float step, float largestep, hipStream_t s) {
+    bool pow2 = true;
+    for (int i = 0; i < 3; ++i) {
+        int e = 0;
+        const bool dim_pow2 = std::frexp(dim[i], &e) == 0.5f;
+        const bool res_pow2 = (res[i] & (res[i] - 1)) == 0;
+        if (!dim_pow2 || !res_pow2 || res[i] < 2) pow2 = false;
+    }
+    return pow2 ? launch_raycast_t<true>(vertex, normal, ray_t, w, h, vol, res, dim, z0, z1, view, near_plane,
+                                         far_plane, step, largestep, s)
+                : launch_raycast_t<false>(vertex, normal, ray_t, w, h, vol, res, dim, z0, z1, view, near_plane,
+                                          far_plane, step, largestep, s);
 }
 
 // Per pixel, keep the slab candidate with the smallest positive hit distance.

@@ -115,6 +115,7 @@ class KFusion:
             "raycasted": bool(st.raycasted),
             "pose": np.array(st.pose, np.float32).reshape(4, 4),
             "sums": np.array(st.sums, np.float32),
+            "icp_iterations": st.icp_iterations, "slow_solves": st.slow_solves,
         }
 
     def trajectory(self, first=0, count=None):
@@ -153,10 +154,15 @@ class KFusion:
                                           C.c_size_t(nbytes)))
         return out
 
-    def set_timing(self, enabled):
-        native.check(self._L.kfh_set_timing(self._ctx, int(bool(enabled))))
+    def set_timing(self, mode):
+        """0 off, 1 (or True) all four phases, 2 integration only."""
+        native.check(self._L.kfh_set_timing(self._ctx, int(mode)))
 
-    def phase_ms(self):
+    def phase_ms(self, frame=None):
+        """HIP-event milliseconds {preprocessing, tracking, integration, raycasting} of a frame."""
         ms = np.empty(4, np.float32)
-        native.check(self._L.kfh_phase_ms(self._ctx, ms.ctypes.data_as(C.c_void_p)))
+        if frame is None:
+            native.check(self._L.kfh_phase_ms(self._ctx, ms.ctypes.data_as(C.c_void_p)))
+        else:
+            native.check(self._L.kfh_phase_ms_frame(self._ctx, int(frame), ms.ctypes.data_as(C.c_void_p)))
         return ms

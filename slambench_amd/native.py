@@ -23,7 +23,7 @@ EXPORTED_SYMBOLS = (
     "kfh_preprocess", "kfh_track", "kfh_integrate", "kfh_raycast", "kfh_end_frame", "kfh_process_frame",
     "kfh_sync",
     "kfh_get_pose", "kfh_set_pose", "kfh_get_status", "kfh_frame_index", "kfh_compute_size",
-    "kfh_download", "kfh_device_ptr", "kfh_stream", "kfh_set_timing", "kfh_phase_ms",
+    "kfh_download", "kfh_device_ptr", "kfh_stream", "kfh_set_timing", "kfh_phase_ms", "kfh_phase_ms_frame",
     "kfh_raycast_slab", "kfh_composite_slabs",
     "kfh_k_preprocess", "kfh_k_bilateral", "kfh_k_half_sample", "kfh_k_vertex_normal",
     "kfh_k_track_reduce", "kfh_k_update_pose", "kfh_k_integrate", "kfh_k_raycast",
@@ -32,7 +32,8 @@ EXPORTED_SYMBOLS = (
 
 class FrameStatus(C.Structure):
     _fields_ = [("frame", C.c_int32), ("tracked", C.c_int32), ("integrated", C.c_int32),
-                ("raycasted", C.c_int32), ("pose", C.c_float * 16), ("sums", C.c_float * 32)]
+                ("raycasted", C.c_int32), ("pose", C.c_float * 16), ("sums", C.c_float * 32),
+                ("icp_iterations", C.c_int32), ("slow_solves", C.c_int32)]
 
 
 class KfhError(RuntimeError):
@@ -71,7 +72,7 @@ def lib():
         "kfh_download": [vp, i32, i32, vp, C.c_size_t],
         "kfh_device_ptr": [vp, i32, i32, C.POINTER(vp), C.POINTER(C.c_size_t)],
         "kfh_stream": [vp, C.POINTER(vp)],
-        "kfh_set_timing": [vp, i32], "kfh_phase_ms": [vp, vp],
+        "kfh_set_timing": [vp, i32], "kfh_phase_ms": [vp, vp], "kfh_phase_ms_frame": [vp, i32, vp],
         "kfh_raycast_slab": [vp], "kfh_composite_slabs": [vp, vp, vp, vp, i32],
         "kfh_k_preprocess": [vp, vp, i32, i32, vp, i32, i32, f32, vp],
         "kfh_k_bilateral": [vp, vp, i32, i32, vp],

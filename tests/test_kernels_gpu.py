@@ -214,11 +214,12 @@ def test_track_reduce_no_model(torch_cuda, L):
 def _update_pose_gpu(torch, L, pose, sums, thr=1e-5):
     p = torch.from_numpy(m4(pose).copy()).cuda()
     x = torch.zeros(6, dtype=torch.float64, device="cuda")
-    conv = torch.zeros(1, dtype=torch.int32, device="cuda")
+    conv = torch.zeros(2, dtype=torch.int32, device="cuda")
     s = torch.from_numpy(np.ascontiguousarray(sums, np.float32)).cuda()
     native.check(L.kfh_k_update_pose(vp(p), vp(x), vp(conv), vp(s), thr, None))
     torch.cuda.synchronize()
-    return p.cpu().numpy().reshape(4, 4), x.cpu().numpy(), bool(conv.item())
+    conv = conv.cpu().numpy()
+    return p.cpu().numpy().reshape(4, 4), x.cpu().numpy(), bool(conv[0]), bool(conv[1])
 
 
 def test_update_pose_well_conditioned(torch_cuda, L, scene):
@@ -226,8 +227,9 @@ def test_update_pose_well_conditioned(torch_cuda, L, scene):
     sums = kf_ref.reduce(kf_ref.track(iv, inn, rv, rn, pose, view), iv.shape[1], iv.shape[0])
     x_want = kf_ref.solve(sums[1:28])
     pose_want, conv_want = kf_ref.update_pose(pose, sums)
-    pose_got, x_got, conv_got = _update_pose_gpu(torch_cuda, L, pose, sums)
-    # double-precision solve: Cholesky on the device vs eigen-decomposition in the oracle
+    pose_got, x_got, conv_got, slow = _update_pose_gpu(torch_cuda, L, pose, sums)
+    assert not slow                               # well conditioned: the elimination path is certified
+    # double-precision solve: Gauss-Jordan on the device vs eigen-decomposition in the oracle
     np.testing.assert_allclose(x_got, x_want, rtol=1e-8, atol=1e-14)
     np.testing.assert_allclose(pose_got, pose_want, rtol=0, atol=1e-6)
     assert conv_got == conv_want
@@ -255,7 +257,8 @@ def test_update_pose_rank_deficient(torch_cuda, L):
     x_want = kf_ref.solve(sums[1:28])
     assert np.abs(x_want).max() < 1.0          # the cut-off keeps the update finite
     pose_want, conv_want = kf_ref.update_pose(pose, sums)
-    pose_got, x_got, conv_got = _update_pose_gpu(torch_cuda, L, pose, sums)
+    pose_got, x_got, conv_got, slow = _update_pose_gpu(torch_cuda, L, pose, sums)
+    assert slow
     np.testing.assert_allclose(x_got, x_want, rtol=1e-6, atol=1e-10)
     np.testing.assert_allclose(pose_got, pose_want, rtol=0, atol=1e-6)
     assert conv_got == conv_want
@@ -264,7 +267,7 @@ def test_update_pose_rank_deficient(torch_cuda, L):
 def test_update_pose_empty_system(torch_cuda, L):
     pose = np.eye(4, dtype=np.float32)
     pose[:3, 3] = [4, 4, 4]
-    pose_got, x_got, conv = _update_pose_gpu(torch_cuda, L, pose, np.zeros(32, np.float32))
+    pose_got, x_got, conv, _ = _update_pose_gpu(torch_cuda, L, pose, np.zeros(32, np.float32))
     assert np.array_equal(x_got, np.zeros(6)) and conv
     assert np.array_equal(pose_got, pose)
 
