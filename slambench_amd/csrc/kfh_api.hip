@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -74,6 +75,7 @@ struct kfh_context {
     size_t partials_stride = 0;            // floats per buffer
     Ctrl *d_ctrl = nullptr;
     kfh_frame_status *d_status = nullptr;
+    unsigned long long *d_stamps = nullptr; // diagnostic ICP time stamps (KFH_ICP_STAMPS=1), [64][8]
 
     // phase timing: a ring of event sets, one per frame (slot = frame % KFH_TIMING_RING)
     int timing = 0;            // 0 off, 1 all four phases, 2 integration only
@@ -116,7 +118,7 @@ void free_all(kfh_context *c) {
     void *bufs[] = {c->d_depth_in, c->d_float_depth, c->d_scaled[0], c->d_scaled[1], c->d_scaled[2],
                     c->d_in_vertex[0], c->d_in_vertex[1], c->d_in_vertex[2], c->d_in_normal[0],
                     c->d_in_normal[1], c->d_in_normal[2], c->d_vertex, c->d_normal, c->d_ray_t, c->d_volume,
-                    c->d_partials, c->d_ctrl, c->d_status};
+                    c->d_partials, c->d_ctrl, c->d_status, c->d_stamps};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     if (c->ev) {
@@ -223,6 +225,10 @@ int kfh_create(const kfh_config *cfg, kfh_context **out) {
     if (e == hipSuccess) e = dev_alloc(&c->d_partials, 2 * c->partials_stride);
     if (e == hipSuccess) e = dev_alloc(&c->d_ctrl, 1);
     if (e == hipSuccess) e = dev_alloc(&c->d_status, KFH_STATUS_RING);
+    if (e == hipSuccess && std::getenv("KFH_ICP_STAMPS")) {
+        e = dev_alloc(&c->d_stamps, 64 * 8);
+        if (e == hipSuccess) e = hipMemset(c->d_stamps, 0, 64 * 8 * sizeof(unsigned long long));
+    }
     if (e != hipSuccess) {
         free_all(c);
         delete c;
@@ -301,6 +307,7 @@ int kfh_track(kfh_context *c) {
         a.dist_threshold = DIST_THRESHOLD;
         a.normal_threshold = NORMAL_THRESHOLD;
         a.icp_threshold = c->cfg.icp_threshold;
+        a.stamps = c->d_stamps;
         int seq = 0;
         for (int level = 2; level >= 0; --level) {
             a.level = level;
@@ -503,6 +510,16 @@ int kfh_phase_ms_frame(kfh_context *c, int frame, float ms[4]) {
 int kfh_phase_ms(kfh_context *c, float ms[4]) {
     KFH_REQUIRE(c != nullptr, "context is NULL");
     return kfh_phase_ms_frame(c, c->frame - 1, ms);
+}
+
+// Diagnostic (not part of include/kfusion_hip.h): copy the ICP time stamps of the last frame, 64 x 8 ticks
+// of the 100 MHz real-time counter.  Only filled when the context was created with KFH_ICP_STAMPS set.
+int kfh_debug_icp_stamps(kfh_context *c, unsigned long long *h_out) {
+    KFH_REQUIRE(c != nullptr && h_out != nullptr, "NULL argument");
+    if (!c->d_stamps) return fail(KFH_ERR_STATE, "context was created without KFH_ICP_STAMPS");
+    KFH_HIP(hipStreamSynchronize(c->stream));
+    KFH_HIP(hipMemcpy(h_out, c->d_stamps, 64 * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return KFH_OK;
 }
 
 // ------------------------------------------------------------------------------------------------------

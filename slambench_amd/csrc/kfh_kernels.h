@@ -59,6 +59,7 @@ struct IcpIterArgs {
     float dist_threshold, normal_threshold, icp_threshold;
     kfh_track_data *track_out;  // per-pixel TrackData for parity tests, may be null
     int track_stride;
+    unsigned long long *stamps; // diagnostic time stamps [seq][8] of block 0, may be null
 };
 
 struct FinishArgs {

@@ -191,35 +191,52 @@ __device__ inline float wave_sum_to_lane63(float v) {
     return v;
 }
 
-// Fixed-order sum of per-block partial rows by one block of NT threads: NT/32 interleaved chains
-// (rows c, c + NT/32, ...) added in chain order, so the result does not depend on scheduling.
-// lds must hold NT floats; the 32 sums are left in lds[0..31].
+// Fixed-order sum of per-block partial rows (32 floats each) by one block of NT threads.  Eight threads
+// cover one row with float4 loads, so NT/8 rows are fetched per pass and all passes are in flight together;
+// the NT/8 row slots are then folded through LDS in two fixed-order stages.  lds must hold NT*4 floats;
+// the 32 sums are left in lds[0..31].  The result does not depend on scheduling.
 template <int NT>
 __device__ inline void sum_partials_block(float *lds, const float *__restrict__ partials, int nrows) {
-    constexpr int CHAINS = NT / 32;
-    const int col = threadIdx.x & 31, chain = threadIdx.x >> 5;
-    float v = 0.f;
-    int b = chain;
-    for (; b + 3 * CHAINS < nrows; b += 4 * CHAINS) {      // four loads in flight, added in row order
-        float t[4];
+    constexpr int SLOTS = NT / 8;                 // rows fetched per pass
+    constexpr int MAXPASS = 8;                    // passes kept in flight
+    const int slot = threadIdx.x >> 3, c4 = threadIdx.x & 7;
+    const float4 *rows4 = reinterpret_cast<const float4 *>(partials);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int r0 = 0; r0 < nrows; r0 += SLOTS * MAXPASS) {
+        float4 t[MAXPASS];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) t[u] = partials[(b + CHAINS * u) * 32 + col];
+        for (int u = 0; u < MAXPASS; ++u) {
+            const int r = r0 + u * SLOTS + slot;
+            t[u] = r < nrows ? rows4[r * 8 + c4] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) v += t[u];
+        for (int u = 0; u < MAXPASS; ++u) {
+            acc.x += t[u].x; acc.y += t[u].y; acc.z += t[u].z; acc.w += t[u].w;
+        }
     }
-    for (; b < nrows; b += CHAINS) v += partials[b * 32 + col];
-    lds[chain * 32 + col] = v;
+    reinterpret_cast<float4 *>(lds)[slot * 8 + c4] = acc;          // lds[slot][32]
+    __syncthreads();
+    // stage 1: 8 groups x 32 columns, each folds SLOTS/8 consecutive slots
+    float g = 0.f;
+    if (threadIdx.x < 256) {
+        const int col = threadIdx.x & 31, grp = threadIdx.x >> 5;
+#pragma unroll
+        for (int k = 0; k < SLOTS / 8; ++k) g += lds[(grp * (SLOTS / 8) + k) * 32 + col];
+    }
+    __syncthreads();
+    if (threadIdx.x < 256) lds[threadIdx.x] = g;                   // lds[grp][32]
     __syncthreads();
     if (threadIdx.x < 32) {
-        float t = lds[col];
-        for (int c = 1; c < CHAINS; ++c) t += lds[c * 32 + col];
-        lds[col] = t;
+        float t = lds[threadIdx.x];
+#pragma unroll
+        for (int c = 1; c < 8; ++c) t += lds[c * 32 + threadIdx.x];
+        lds[threadIdx.x] = t;
     }
     __syncthreads();
 }
 
 __global__ __launch_bounds__(KFH_TRACK_THREADS) void k_sum_partials(float *sums, const float *partials, int nrows) {
-    __shared__ float lds[KFH_TRACK_THREADS];
+    __shared__ float lds[KFH_TRACK_THREADS * 4];
     sum_partials_block<KFH_TRACK_THREADS>(lds, partials, nrows);
     if (threadIdx.x < 32) sums[threadIdx.x] = lds[threadIdx.x];
 }
@@ -239,6 +256,16 @@ hipError_t launch_sum_partials(float *sums, const float *partials, int nrows, hi
 // certifies the result.  Otherwise lane 0 applies the truncation rule literally through a cyclic Jacobi
 // eigen-decomposition (slow path: rank-deficient or nearly singular systems).
 // =====================================================================================================
+__device__ inline float readlane63(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+// value of a double held by a lane whose index is the same for the whole wavefront
+__device__ inline double readlane_f64(double v, int lane) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+
 __device__ inline double wave_sum_f64(double v) {
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
@@ -325,13 +352,17 @@ __device__ void solve_normal_equations_wave(const float *vals, double x[6], int 
     const bool in_c = i < 6 && j < 6;
     const double c_elem = in_c ? a : 0.0;
     double inv = (i == j && i < 6) ? 1.0 : 0.0;
-    const double fro_c2 = wave_sum_f64(c_elem * c_elem);
+    // the conditioning certificate only needs a few digits: float norms, DPP reductions
+    const float fro_c2 = readlane63(wave_sum_to_lane63((float)c_elem * (float)c_elem));
     bool spd = true;
 #pragma unroll
     for (int k = 0; k < 6; ++k) {
-        const double p = __shfl(a, k * 8 + k, 64);
+        const double p = readlane_f64(a, k * 8 + k);
         if (!(p > 0.0)) spd = false;                 // wave-uniform
-        const double rinv = 1.0 / p;
+        // reciprocal by hardware estimate + two Newton steps (the pivot is positive and finite here)
+        double rinv = __builtin_amdgcn_rcp(p);
+        rinv = fma(fma(-p, rinv, 1.0), rinv, rinv);
+        rinv = fma(fma(-p, rinv, 1.0), rinv, rinv);
         const double rk_a = __shfl(a, k * 8 + j, 64) * rinv;
         const double rk_i = __shfl(inv, k * 8 + j, 64) * rinv;
         const double ck = __shfl(a, i * 8 + k, 64);
@@ -343,8 +374,9 @@ __device__ void solve_normal_equations_wave(const float *vals, double x[6], int 
             inv = inv - ck * rk_i;
         }
     }
-    const double fro_i2 = wave_sum_f64(in_c ? inv * inv : 0.0);
-    const bool certified = spd && (fro_c2 * fro_i2 < 1e12);   // (||C||_F ||C^-1||_F)^2 < (1e6)^2
+    const float fro_i2 = readlane63(wave_sum_to_lane63(in_c ? (float)inv * (float)inv : 0.f));
+    // (||C||_F ||C^-1||_F)^2 < (1e6)^2, with 1 % slack for the float norms
+    const bool certified = spd && ((double)fro_c2 * (double)fro_i2 < 0.98e12);
     if (certified) {
 #pragma unroll
         for (int m = 0; m < 6; ++m) x[m] = __shfl(a, m * 8 + 6, 64);
@@ -362,7 +394,6 @@ __device__ Mat4 se3_exp(const double mu[6]) {
     const double one_6th = 1.0 / 6.0, one_20th = 1.0 / 20.0;
     const double w0 = mu[3], w1 = mu[4], w2 = mu[5];
     const double theta_sq = w0 * w0 + w1 * w1 + w2 * w2;
-    const double theta = sqrt(theta_sq);
     double A, B;
     const double cr[3] = {w1 * mu[2] - w2 * mu[1], w2 * mu[0] - w0 * mu[2], w0 * mu[1] - w1 * mu[0]};
     double t[3];
@@ -376,7 +407,19 @@ __device__ Mat4 se3_exp(const double mu[6]) {
             C = one_6th * (1.0 - one_20th * theta_sq);
             A = 1.0 - theta_sq * C;
             B = 0.5 - 0.25 * one_6th * theta_sq;
+        } else if (theta_sq < 0.25) {
+            // |theta| < 0.5 rad: the Taylor series of sin(t)/t, (1-cos t)/t^2 and (t-sin t)/t^3 in t^2
+            // converge below 1e-15 in eight terms; the pose is rounded to float afterwards.  This replaces
+            // a double-precision sin/cos/sqrt chain on the critical path of every ICP iteration.
+            const double t2 = theta_sq;
+            A = 1.0 + t2 * (-1.0 / 6 + t2 * (1.0 / 120 + t2 * (-1.0 / 5040 + t2 * (1.0 / 362880 +
+                t2 * (-1.0 / 39916800 + t2 * (1.0 / 6227020800.0 + t2 * (-1.0 / 1307674368000.0)))))));
+            B = 0.5 + t2 * (-1.0 / 24 + t2 * (1.0 / 720 + t2 * (-1.0 / 40320 + t2 * (1.0 / 3628800 +
+                t2 * (-1.0 / 479001600 + t2 * (1.0 / 87178291200.0 + t2 * (-1.0 / 20922789888000.0)))))));
+            C = 1.0 / 6 + t2 * (-1.0 / 120 + t2 * (1.0 / 5040 + t2 * (-1.0 / 362880 + t2 * (1.0 / 39916800 +
+                t2 * (-1.0 / 6227020800.0 + t2 * (1.0 / 1307674368000.0 + t2 * (-1.0 / 355687428096000.0)))))));
         } else {
+            const double theta = sqrt(theta_sq);
             const double inv_theta = 1.0 / theta;
             A = sin(theta) * inv_theta;
             B = (1 - cos(theta)) * (inv_theta * inv_theta);
@@ -412,7 +455,7 @@ __device__ bool update_pose_wave(Mat4 &pose, const float *sums, float icp_thresh
     pose = mat_mul(delta, pose);
     double n2 = 0.0;
     for (int i = 0; i < 6; ++i) n2 += x[i] * x[i];
-    return sqrt(n2) < (double)icp_threshold;
+    return n2 < (double)icp_threshold * (double)icp_threshold;   // |x| < threshold
 }
 
 // Matrices the later phases of the frame (and the next frame's tracking) read, and the ICP state the next
@@ -483,7 +526,7 @@ __device__ void finish_tracking(const FinishArgs &a, bool ran_tracking, int iter
 // Algorithmic bytes: 64 B per pixel (in vertex+normal, gathered reference vertex+normal) + 128 B per block.
 // =====================================================================================================
 struct IcpShared {
-    float red[KFH_TRACK_THREADS];   // partial-row chains, then the sums in red[0..31]
+    float red[KFH_TRACK_THREADS * 4];   // partial-row slots, then the sums in red[0..31]
     Mat4 pose;
     int done_mask, iterations, slow_solves;
 };
@@ -493,10 +536,11 @@ struct IcpShared {
 __device__ inline void icp_finalize_pending(const IcpState *__restrict__ in, const float *__restrict__ partials_in,
                                             float icp_threshold, IcpShared &sh) {
     const int pend = in->pending_nblocks;            // uniform
+    const Mat4 pose_in = in->pose;                   // requested now, needed after the partial sums
     if (pend > 0) {
         sum_partials_block<KFH_TRACK_THREADS>(sh.red, partials_in, pend);
         if (threadIdx.x < 64) {                      // the solve runs on wavefront 0
-            Mat4 pose = in->pose;
+            Mat4 pose = pose_in;
             double x[6];
             int slow;
             const bool converged = update_pose_wave(pose, sh.red, icp_threshold, x, &slow);
@@ -511,7 +555,7 @@ __device__ inline void icp_finalize_pending(const IcpState *__restrict__ in, con
     } else {
         if (threadIdx.x < 32) sh.red[threadIdx.x] = in->sums[threadIdx.x];
         if (threadIdx.x == 0) {
-            sh.pose = in->pose;
+            sh.pose = pose_in;
             sh.done_mask = in->done_mask;
             sh.iterations = in->iterations;
             sh.slow_solves = in->slow_solves;
@@ -535,9 +579,21 @@ __device__ inline void icp_store_state(IcpState *out, const IcpShared &sh, int p
     }
 }
 
+// Diagnostic time stamps (100 MHz real-time counter) of block 0, taken only in the STAMPS instantiation.
+#define KFH_STAMP(slot)                                                                       \
+    do {                                                                                      \
+        if (STAMPS && blockIdx.x == 0 && threadIdx.x == 0) {                                  \
+            __builtin_amdgcn_sched_barrier(0);                                                \
+            a.stamps[a.seq * 8 + (slot)] = __builtin_amdgcn_s_memrealtime();                  \
+            __builtin_amdgcn_sched_barrier(0);                                                \
+        }                                                                                     \
+    } while (0)
+
+template <bool STAMPS>
 __global__ __launch_bounds__(KFH_TRACK_THREADS) void k_icp_iteration(IcpIterArgs a) {
     constexpr int PPT = KFH_TRACK_PIX_PER_THREAD;
     __shared__ IcpShared sh;
+    KFH_STAMP(0);
     const int npix = a.iw * a.ih;
     const int base = blockIdx.x * (KFH_TRACK_THREADS * PPT) + threadIdx.x;
 
@@ -556,6 +612,7 @@ __global__ __launch_bounds__(KFH_TRACK_THREADS) void k_icp_iteration(IcpIterArgs
     const IcpState *in = &a.ctrl->icp[a.seq & 1];
     IcpState *out = &a.ctrl->icp[(a.seq + 1) & 1];
     icp_finalize_pending(in, a.partials_in, a.icp_threshold, sh);
+    KFH_STAMP(1);
 
     if (sh.done_mask & (1 << a.level)) {             // this level already finished: nothing to evaluate
         if (blockIdx.x == 0) icp_store_state(out, sh, 0, a.level, 0);
@@ -588,6 +645,7 @@ __global__ __launch_bounds__(KFH_TRACK_THREADS) void k_icp_iteration(IcpIterArgs
         rv4[k] = a.ref_vertex[ridx[k]];
     }
 
+    KFH_STAMP(2);
     float acc[32];
 #pragma unroll
     for (int i = 0; i < 32; ++i) acc[i] = 0.0f;
@@ -635,6 +693,7 @@ __global__ __launch_bounds__(KFH_TRACK_THREADS) void k_icp_iteration(IcpIterArgs
         acc[31] += (count && result < 1 && result > -4) ? 1.f : 0.f;
     }
 
+    KFH_STAMP(3);
     constexpr int NWAVES = KFH_TRACK_THREADS / 64;
     __shared__ float wsum[NWAVES][32];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -643,6 +702,7 @@ __global__ __launch_bounds__(KFH_TRACK_THREADS) void k_icp_iteration(IcpIterArgs
         const float v = wave_sum_to_lane63(acc[i]);
         if (lane == 63) wsum[wave][i] = v;
     }
+    KFH_STAMP(4);
     if (blockIdx.x == 0) icp_store_state(out, sh, gridDim.x, a.level, a.last_iter);
     __syncthreads();
     if (threadIdx.x < 32) {
@@ -651,11 +711,15 @@ __global__ __launch_bounds__(KFH_TRACK_THREADS) void k_icp_iteration(IcpIterArgs
         for (int wv = 1; wv < NWAVES; ++wv) v += wsum[wv][threadIdx.x];
         a.partials_out[blockIdx.x * 32 + threadIdx.x] = v;
     }
+    KFH_STAMP(5);
 }
 
 hipError_t launch_icp_iteration(const IcpIterArgs &a, hipStream_t s) {
     const int nb = track_blocks(a.iw, a.ih);
-    hipLaunchKernelGGL(k_icp_iteration, dim3(nb), dim3(KFH_TRACK_THREADS), 0, s, a);
+    if (a.stamps)
+        hipLaunchKernelGGL(k_icp_iteration<true>, dim3(nb), dim3(KFH_TRACK_THREADS), 0, s, a);
+    else
+        hipLaunchKernelGGL(k_icp_iteration<false>, dim3(nb), dim3(KFH_TRACK_THREADS), 0, s, a);
     return hipGetLastError();
 }
 
@@ -719,6 +783,7 @@ hipError_t launch_track_reduce(Ctrl *scratch_ctrl, float *partials, float *sums,
     a.dist_threshold = dist_threshold; a.normal_threshold = normal_threshold;
     a.icp_threshold = 0.f;
     a.track_out = track_out; a.track_stride = track_stride;
+    a.stamps = nullptr;
     hipError_t e = launch_icp_iteration(a, s);
     if (e != hipSuccess) return e;
     return launch_sum_partials(sums, partials, track_blocks(iw, ih), s);
@@ -764,6 +829,20 @@ hipError_t launch_pose_derive(Ctrl *ctrl, const float k[4], int set_raycast_pose
 // =====================================================================================================
 constexpr int INTEGRATE_UNROLL = 8;
 
+// Correctly rounded float division with the denominator's reciprocal shared between several numerators.
+// This is the instruction sequence of the compiler's own IEEE division (reciprocal estimate, one Newton
+// step, two quotient corrections) without the exponent pre-scaling, which only matters for operands near
+// the ends of the float range; the integrate kernel divides metres and pixels by a depth >= 1e-4.
+__device__ inline float refined_rcp(float d) {
+    const float r = __builtin_amdgcn_rcpf(d);
+    return fmaf(fmaf(-d, r, 1.f), r, r);
+}
+__device__ inline float div_shared(float n, float d, float r1) {
+    const float q0 = n * r1;
+    const float q1 = fmaf(fmaf(-d, q0, n), r1, q0);
+    return fmaf(fmaf(-d, q1, n), r1, q1);
+}
+
 __global__ __launch_bounds__(256) void k_integrate(short2 *__restrict__ vol, int sx, int sy, int sz,
                                                    float dimx, float dimy, float dimz, int z0, int z1,
                                                    const float *__restrict__ depth, int w, int h,
@@ -778,22 +857,67 @@ __global__ __launch_bounds__(256) void k_integrate(short2 *__restrict__ vol, int
     const int zc1 = min(z1, ((int)blockIdx.z + 1) * zchunk);
     if (zc0 >= zc1) return;
     const Mat4 invTrack = *inv_track_p;
+    const float wmax = (float)(w - 1), hmax = (float)(h - 1);
+    {
+        // Conservative frustum culling of this block's 64 x 4 x zchunk box, grown by two voxels per side.
+        // A voxel is only ever touched if it passes the half-space tests of the march below; if all eight
+        // corners of the grown box fail the same half-space, no voxel of the block can pass it (the two
+        // voxels of slack are far more than the drift of the incrementally accumulated positions), and the
+        // block leaves without replaying the column prefix.
+        const float vx = dimx / (float)sx, vy = dimy / (float)sy, vz = dimz / (float)sz;
+        const float bx0 = ((float)((int)blockIdx.x * 64 - 2) + 0.5f) * vx;
+        const float bx1 = ((float)(min((int)blockIdx.x * 64 + 63, sx - 1) + 2) + 0.5f) * vx;
+        const float by0 = ((float)((int)blockIdx.y * 4 - 2) + 0.5f) * vy;
+        const float by1 = ((float)(min((int)blockIdx.y * 4 + 3, sy - 1) + 2) + 0.5f) * vy;
+        const float bz0 = ((float)(zc0 - 2) + 0.5f) * vz;
+        const float bz1 = ((float)(zc1 + 1) + 0.5f) * vz;
+        const f3 c0 = xform(invTrack, mk3(bx0, by0, bz0));
+        const f3 ex = rotate(invTrack, mk3(bx1 - bx0, 0.f, 0.f));
+        const f3 ey = rotate(invTrack, mk3(0.f, by1 - by0, 0.f));
+        const f3 ez = rotate(invTrack, mk3(0.f, 0.f, bz1 - bz0));
+        bool behind = true, left = true, right = true, up = true, down = true;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            f3 P = c0;
+            if (q & 1) P = P + ex;
+            if (q & 2) P = P + ey;
+            if (q & 4) P = P + ez;
+            const float cxp = K.m[0] * P.x + K.m[2] * P.z;
+            const float cyp = K.m[5] * P.y + K.m[6] * P.z;
+            behind = behind && (P.z < 0.0001f);
+            left = left && (cxp < -1.5f * P.z);
+            right = right && (cxp > (wmax + 1.5f) * P.z);
+            up = up && (cyp < -1.5f * P.z);
+            down = down && (cyp > (hmax + 1.5f) * P.z);
+        }
+        if (behind || left || right || up || down) return;
+    }
     const f3 delta = rotate(invTrack, mk3(0, 0, dimz / (float)sz));
     const f3 cameraDelta = rotate(K, delta);
     const f3 p0 = mk3(((float)x + 0.5f) * dimx / (float)sx, ((float)y + 0.5f) * dimy / (float)sy,
                       (0.0f + 0.5f) * dimz / (float)sz);
     f3 pos = xform(invTrack, p0);
     f3 cameraX = xform(K, pos);
-    const float wmax = (float)(w - 1), hmax = (float)(h - 1);
     const size_t plane = (size_t)sx * sy;
     short2 *col = vol + (size_t)x + (size_t)y * sx;
+    {
+        // replay the additions of the steps below this chunk: same operations in the same order as a march
+        // from z = 0, two components per packed add
+        typedef float v2f __attribute__((ext_vector_type(2)));
+        v2f a0 = {pos.x, pos.y}, a1 = {pos.z, cameraX.x}, a2 = {cameraX.y, cameraX.z};
+        const v2f d0 = {delta.x, delta.y}, d1 = {delta.z, cameraDelta.x}, d2 = {cameraDelta.y, cameraDelta.z};
+#pragma unroll 8
+        for (int z = 0; z < zc0; ++z) {
+            a0 += d0;
+            a1 += d1;
+            a2 += d2;
+        }
+        pos = mk3(a0.x, a0.y, a1.x);
+        cameraX = mk3(a1.y, a2.x, a2.y);
+    }
     // INTEGRATE_UNROLL z steps are advanced arithmetically, then their depth pixels and voxels are fetched
     // together (the voxel read is issued as soon as the pixel test passes, before the depth value is
     // known) and finally updated: one memory round trip per group instead of two per voxel.
-    for (int z = 0; z < zc0; ++z) {
-        pos = pos + delta;
-        cameraX = cameraX + cameraDelta;
-    }
     for (int zb = zc0; zb < zc1; zb += INTEGRATE_UNROLL) {
         f3 posk[INTEGRATE_UNROLL];
         float camz[INTEGRATE_UNROLL];
@@ -812,8 +936,9 @@ __global__ __launch_bounds__(256) void k_integrate(short2 *__restrict__ vol, int
                 c = false;
             unsigned pi = 0;
             if (c) {
-                const float pxf = cameraX.x / cameraX.z + 0.5f;
-                const float pyf = cameraX.y / cameraX.z + 0.5f;
+                const float r1 = refined_rcp(cameraX.z);
+                const float pxf = div_shared(cameraX.x, cameraX.z, r1) + 0.5f;
+                const float pyf = div_shared(cameraX.y, cameraX.z, r1) + 0.5f;
                 if (pxf < 0 || pxf > wmax || pyf < 0 || pyf > hmax) c = false;
                 else pi = (unsigned)pxf + (unsigned)pyf * (unsigned)w;
             }
@@ -836,10 +961,21 @@ __global__ __launch_bounds__(256) void k_integrate(short2 *__restrict__ vol, int
 #pragma unroll
         for (int u = 0; u < INTEGRATE_UNROLL; ++u) {
             if (!cand[u] || dk[u] == 0) continue;
-            const float rx = posk[u].x / posk[u].z, ry = posk[u].y / posk[u].z;
-            const float diff = (dk[u] - camz[u]) * sqrtf(1 + rx * rx + ry * ry);
-            if (diff > -mu) {
-                const float sdf = fminf(1.f, diff / mu);
+            // diff = (d - z) * s with s = sqrt(1 + rx^2 + ry^2) >= 1, so
+            //   d - z <= -mu  implies  diff <= -mu        (voxel behind the surface: untouched)
+            //   d - z >=  mu  implies  min(1, diff / mu) == 1   (free space)
+            // and only the band in between needs s.
+            const float dz = dk[u] - camz[u];
+            if (dz <= -mu) continue;
+            float sdf = 1.f;
+            if (dz < mu) {
+                const float r1 = refined_rcp(posk[u].z);
+                const float rx = div_shared(posk[u].x, posk[u].z, r1), ry = div_shared(posk[u].y, posk[u].z, r1);
+                const float diff = dz * sqrtf(1 + rx * rx + ry * ry);
+                if (!(diff > -mu)) continue;
+                sdf = fminf(1.f, diff / mu);
+            }
+            {
                 float tsdf = (float)rawk[u].x * KFH_SHORT2FLOAT;
                 float wgt = (float)rawk[u].y;
                 tsdf = fmaxf(-1.f, fminf((wgt * tsdf + sdf) / (wgt + 1), 1.f));
@@ -853,13 +989,10 @@ __global__ __launch_bounds__(256) void k_integrate(short2 *__restrict__ vol, int
 hipError_t launch_integrate(short2 *vol, const int res[3], const float dim[3], int z0, int z1,
                             const float *depth, int w, int h, const Mat4 *inv_track, Mat4 K, float mu,
                             float maxweight, const int *gate, hipStream_t s) {
-    // enough z chunks to keep about eight wavefronts per SIMD resident (1024 SIMDs), each chunk a multiple
-    // of the unroll factor
+    // Short z chunks: blocks whose box misses the camera frustum leave at once, the others replay the column
+    // prefix (a few packed adds per step) and then march only zchunk steps, so no wavefront runs long.
     const int gx = (res[0] + 63) / 64, gy = (res[1] + 3) / 4;
-    int split = 8192 / (gx * gy * 4);
-    split = split < 1 ? 1 : (split > 16 ? 16 : split);
-    int zchunk = (z1 + split - 1) / split;
-    zchunk = ((zchunk + INTEGRATE_UNROLL - 1) / INTEGRATE_UNROLL) * INTEGRATE_UNROLL;
+    const int zchunk = z1 <= 512 ? 32 : 64;
     const int gz = (z1 + zchunk - 1) / zchunk;
     const dim3 grid(gx, gy, gz);
     hipLaunchKernelGGL(k_integrate, grid, dim3(256), 0, s, vol, res[0], res[1], res[2], dim[0], dim[1], dim[2],
