@@ -151,10 +151,12 @@ int kfh_k_half_sample(float *d_out, const float *d_in, int iw, int ih, float e_d
 /* depth2vertexKernel + vertex2normalKernel, k = intrinsics of this level */
 int kfh_k_vertex_normal(void *d_vertex4, void *d_normal4, const float *d_depth, int w, int h,
                         float fx, float fy, float cx, float cy, void *stream);
-/* trackKernel + reduceKernel fused.  d_sums receives 32 floats (reduceKernel layout); d_track (may be NULL)
- * receives the per-pixel TrackData with row stride `track_stride`. */
+/* trackKernel + reduceKernel fused.  The input vertex map is not read: the kernel re-evaluates
+ * depth2vertexKernel from d_in_depth (float[ih][iw]) and the level's intrinsics k = {fx, fy, cx, cy}.
+ * d_sums receives 32 floats (reduceKernel layout); d_track (may be NULL) receives the per-pixel TrackData
+ * with row stride `track_stride`. */
 int kfh_k_track_reduce(float *d_sums, kfh_track_data *d_track, int track_stride,
-                       const void *d_in_vertex4, const void *d_in_normal4, int iw, int ih,
+                       const float *d_in_depth, const float k[4], const void *d_in_normal4, int iw, int ih,
                        const void *d_ref_vertex4, const void *d_ref_normal4, int rw, int rh,
                        const float Ttrack[16], const float view[16],
                        float dist_threshold, float normal_threshold, void *stream);

@@ -311,8 +311,9 @@ int kfh_track(kfh_context *c) {
         int seq = 0;
         for (int level = 2; level >= 0; --level) {
             a.level = level;
-            a.in_vertex = c->d_in_vertex[level];
+            a.in_depth = c->d_scaled[level];
             a.in_normal = c->d_in_normal[level];
+            for (int i = 0; i < 4; ++i) a.k[i] = c->k[i] / (float)(1 << level);
             a.iw = c->w >> level;
             a.ih = c->h >> level;
             for (int i = 0; i < c->cfg.pyramid[level]; ++i, ++seq) {
@@ -556,13 +557,14 @@ int kfh_k_vertex_normal(void *d_vertex4, void *d_normal4, const float *d_depth, 
     return KFH_OK;
 }
 
-int kfh_k_track_reduce(float *d_sums, kfh_track_data *d_track, int track_stride, const void *d_in_vertex4,
-                       const void *d_in_normal4, int iw, int ih, const void *d_ref_vertex4,
+int kfh_k_track_reduce(float *d_sums, kfh_track_data *d_track, int track_stride, const float *d_in_depth,
+                       const float k[4], const void *d_in_normal4, int iw, int ih, const void *d_ref_vertex4,
                        const void *d_ref_normal4, int rw, int rh, const float Ttrack[16], const float view[16],
                        float dist_threshold, float normal_threshold, void *stream) {
-    KFH_REQUIRE(d_sums && d_in_vertex4 && d_in_normal4 && d_ref_vertex4 && d_ref_normal4 && Ttrack && view,
+    KFH_REQUIRE(d_sums && d_in_depth && k && d_in_normal4 && d_ref_vertex4 && d_ref_normal4 && Ttrack && view,
                 "NULL argument");
     KFH_REQUIRE(iw > 0 && ih > 0 && rw > 0 && rh > 0, "bad sizes");
+    KFH_REQUIRE(k[0] != 0.f && k[1] != 0.f, "focal lengths must be non-zero");
     KFH_REQUIRE(!d_track || track_stride >= iw, "track_stride must be >= iw");
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int nb = track_blocks(iw, ih);
@@ -573,7 +575,7 @@ int kfh_k_track_reduce(float *d_sums, kfh_track_data *d_track, int track_stride,
     std::memcpy(T.m, Ttrack, sizeof(T.m));
     std::memcpy(V.m, view, sizeof(V.m));
     hipError_t e = launch_track_reduce(reinterpret_cast<Ctrl *>(scratch), reinterpret_cast<float *>(scratch + ctrl_bytes),
-                                       d_sums, d_track, track_stride, static_cast<const float4 *>(d_in_vertex4),
+                                       d_sums, d_track, track_stride, d_in_depth, k,
                                        static_cast<const float4 *>(d_in_normal4), iw, ih,
                                        static_cast<const float4 *>(d_ref_vertex4),
                                        static_cast<const float4 *>(d_ref_normal4), rw, rh, T, V, dist_threshold,

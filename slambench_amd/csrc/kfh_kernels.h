@@ -37,8 +37,8 @@ struct Ctrl {
     IcpState icp[2];    // alternating records of the ICP loop
 };
 
-constexpr int KFH_TRACK_THREADS = 512;
-constexpr int KFH_TRACK_PIX_PER_THREAD = 2;
+constexpr int KFH_TRACK_THREADS = 256;
+constexpr int KFH_TRACK_PIX_PER_THREAD = 4;
 constexpr int KFH_STATUS_RING = 4096;
 
 inline int track_blocks(int w, int h) {
@@ -52,7 +52,9 @@ struct IcpIterArgs {
     float *partials_out;        // rows of this one
     int seq;                    // position of this launch in the frame's iteration sequence
     int level, last_iter;       // pyramid level; last iteration configured for the level
-    const float4 *in_vertex, *in_normal;
+    const float *in_depth;      // pyramid level of the filtered depth (the input vertex is recomputed from it)
+    const float4 *in_normal;
+    float k[4];                 // intrinsics of this level
     int iw, ih;
     const float4 *ref_vertex, *ref_normal;
     int rw, rh;
@@ -87,7 +89,8 @@ hipError_t launch_icp_finish(const FinishArgs &a, hipStream_t s);
 hipError_t launch_track_skip(const FinishArgs &a, hipStream_t s);
 // one stand-alone iteration on caller-provided matrices + fixed-order sum of its partial rows (parity tests)
 hipError_t launch_track_reduce(Ctrl *scratch_ctrl, float *partials, float *sums, kfh_track_data *track_out,
-                               int track_stride, const float4 *in_vertex, const float4 *in_normal, int iw, int ih,
+                               int track_stride, const float *in_depth, const float k[4], const float4 *in_normal,
+                               int iw, int ih,
                                const float4 *ref_vertex, const float4 *ref_normal, int rw, int rh,
                                const Mat4 &Ttrack, const Mat4 &view, float dist_threshold, float normal_threshold,
                                hipStream_t s);

@@ -198,7 +198,7 @@ __device__ inline float wave_sum_to_lane63(float v) {
 template <int NT>
 __device__ inline void sum_partials_block(float *lds, const float *__restrict__ partials, int nrows) {
     constexpr int SLOTS = NT / 8;                 // rows fetched per pass
-    constexpr int MAXPASS = 8;                    // passes kept in flight
+    constexpr int MAXPASS = 10;                   // passes kept in flight
     const int slot = threadIdx.x >> 3, c4 = threadIdx.x & 7;
     const float4 *rows4 = reinterpret_cast<const float4 *>(partials);
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -526,6 +526,7 @@ __device__ void finish_tracking(const FinishArgs &a, bool ran_tracking, int iter
 // Algorithmic bytes: 64 B per pixel (in vertex+normal, gathered reference vertex+normal) + 128 B per block.
 // =====================================================================================================
 struct IcpShared {
+    float tr[32 * KFH_TRACK_THREADS];   // transpose buffer of the block reduction (64 KiB)
     float red[KFH_TRACK_THREADS * 4];   // partial-row slots, then the sums in red[0..31]
     Mat4 pose;
     int done_mask, iterations, slow_solves;
@@ -534,11 +535,13 @@ struct IcpShared {
 // Called by every thread of a KFH_TRACK_THREADS block.  Leaves pose / sums / counters after the pending
 // iteration (if any) in `sh`.
 __device__ inline void icp_finalize_pending(const IcpState *__restrict__ in, const float *__restrict__ partials_in,
-                                            float icp_threshold, IcpShared &sh) {
+                                            float icp_threshold, IcpShared &sh,
+                                            unsigned long long *stamps = nullptr) {
     const int pend = in->pending_nblocks;            // uniform
     const Mat4 pose_in = in->pose;                   // requested now, needed after the partial sums
     if (pend > 0) {
         sum_partials_block<KFH_TRACK_THREADS>(sh.red, partials_in, pend);
+        if (stamps && blockIdx.x == 0 && threadIdx.x == 0) stamps[6] = __builtin_amdgcn_s_memrealtime();
         if (threadIdx.x < 64) {                      // the solve runs on wavefront 0
             Mat4 pose = pose_in;
             double x[6];
@@ -550,6 +553,7 @@ __device__ inline void icp_finalize_pending(const IcpState *__restrict__ in, con
                 sh.done_mask = in->done_mask | (level_finished ? (1 << in->pending_level) : 0);
                 sh.iterations = in->iterations + 1;
                 sh.slow_solves = in->slow_solves + slow;
+                if (stamps && blockIdx.x == 0) stamps[7] = __builtin_amdgcn_s_memrealtime();
             }
         }
     } else {
@@ -598,20 +602,22 @@ __global__ __launch_bounds__(KFH_TRACK_THREADS) void k_icp_iteration(IcpIterArgs
     const int base = blockIdx.x * (KFH_TRACK_THREADS * PPT) + threadIdx.x;
 
     // this iteration's input pixels: in flight while the previous iteration is finalised
-    float4 nin4[PPT], vin4[PPT];
+    float4 nin4[PPT];
+    float din[PPT];
+    int pcl[PPT];
     bool live[PPT];
 #pragma unroll
     for (int k = 0; k < PPT; ++k) {
         const int p = base + k * KFH_TRACK_THREADS;
         live[k] = p < npix;
-        const int pc = live[k] ? p : 0;
-        nin4[k] = a.in_normal[pc];
-        vin4[k] = a.in_vertex[pc];
+        pcl[k] = live[k] ? p : 0;
+        nin4[k] = a.in_normal[pcl[k]];
+        din[k] = a.in_depth[pcl[k]];
     }
 
     const IcpState *in = &a.ctrl->icp[a.seq & 1];
     IcpState *out = &a.ctrl->icp[(a.seq + 1) & 1];
-    icp_finalize_pending(in, a.partials_in, a.icp_threshold, sh);
+    icp_finalize_pending(in, a.partials_in, a.icp_threshold, sh, STAMPS ? a.stamps + a.seq * 8 : nullptr);
     KFH_STAMP(1);
 
     if (sh.done_mask & (1 << a.level)) {             // this level already finished: nothing to evaluate
@@ -628,9 +634,14 @@ __global__ __launch_bounds__(KFH_TRACK_THREADS) void k_icp_iteration(IcpIterArgs
     f3 projectedVertex[PPT];
     bool img_ok[PPT];
     unsigned ridx[PPT];
+    const Mat4 invK = inverse_camera_matrix(a.k[0], a.k[1], a.k[2], a.k[3]);
 #pragma unroll
     for (int k = 0; k < PPT; ++k) {
-        projectedVertex[k] = xform(Ttrack, mk3(vin4[k].x, vin4[k].y, vin4[k].z));
+        // the input vertex is depth2vertexKernel's expression, re-evaluated from the 4-byte depth instead of
+        // reading the 16-byte vertex map
+        const int py_in = pcl[k] / a.iw, px_in = pcl[k] - py_in * a.iw;
+        const f3 vin = back_project(din[k], px_in, py_in, invK);
+        projectedVertex[k] = xform(Ttrack, vin);
         const f3 projectedPos = xform(view, projectedVertex[k]);
         const float px = projectedPos.x / projectedPos.z + 0.5f;
         const float py = projectedPos.y / projectedPos.z + 0.5f;
@@ -694,22 +705,28 @@ __global__ __launch_bounds__(KFH_TRACK_THREADS) void k_icp_iteration(IcpIterArgs
     }
 
     KFH_STAMP(3);
-    constexpr int NWAVES = KFH_TRACK_THREADS / 64;
-    __shared__ float wsum[NWAVES][32];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // Block reduction of the 32 sums through LDS: thread t stores value v at tr[v][t]; then THREADS/32 threads
+    // per value each fold 32 consecutive entries (start rotated by the part index, so the threads of a value
+    // hit different banks) and a DPP row reduction folds the parts.  Fixed order, no atomics.
+    float *tr = sh.tr;
 #pragma unroll
-    for (int i = 0; i < 32; ++i) {
-        const float v = wave_sum_to_lane63(acc[i]);
-        if (lane == 63) wsum[wave][i] = v;
-    }
-    KFH_STAMP(4);
+    for (int i = 0; i < 32; ++i) tr[i * KFH_TRACK_THREADS + threadIdx.x] = acc[i];
     if (blockIdx.x == 0) icp_store_state(out, sh, gridDim.x, a.level, a.last_iter);
     __syncthreads();
-    if (threadIdx.x < 32) {
-        float v = wsum[0][threadIdx.x];
+    {
+        constexpr int PARTS = KFH_TRACK_THREADS / 32;     // threads that share one value (8 or 16)
+        static_assert(PARTS == 8 || PARTS == 16, "block reduction expects 256 or 512 threads");
+        const int v = threadIdx.x / PARTS, part = threadIdx.x % PARTS;
+        const float *src = tr + v * KFH_TRACK_THREADS + part * 32;
+        float sum = 0.f;
 #pragma unroll
-        for (int wv = 1; wv < NWAVES; ++wv) v += wsum[wv][threadIdx.x];
-        a.partials_out[blockIdx.x * 32 + threadIdx.x] = v;
+        for (int k = 0; k < 32; ++k) sum += src[(k + part) & 31];
+        sum = dpp_add<0xB1, 0xF>(sum);    // quad_perm [1,0,3,2]
+        sum = dpp_add<0x4E, 0xF>(sum);    // quad_perm [2,3,0,1]
+        sum = dpp_add<0x114, 0xF>(sum);   // row_shr:4 -> lanes 7 and 15 of a row hold 8-lane sums
+        if (PARTS == 16) sum = dpp_add<0x118, 0xF>(sum);   // row_shr:8 -> lane 15 holds the 16-lane sum
+        KFH_STAMP(4);
+        if (part == PARTS - 1) a.partials_out[blockIdx.x * 32 + v] = sum;
     }
     KFH_STAMP(5);
 }
@@ -766,7 +783,8 @@ __global__ void k_icp_seed(Ctrl *c, Mat4 Ttrack, Mat4 view) {
 }
 
 hipError_t launch_track_reduce(Ctrl *scratch_ctrl, float *partials, float *sums, kfh_track_data *track_out,
-                               int track_stride, const float4 *in_vertex, const float4 *in_normal, int iw, int ih,
+                               int track_stride, const float *in_depth, const float k[4], const float4 *in_normal,
+                               int iw, int ih,
                                const float4 *ref_vertex, const float4 *ref_normal, int rw, int rh,
                                const Mat4 &Ttrack, const Mat4 &view, float dist_threshold, float normal_threshold,
                                hipStream_t s) {
@@ -778,7 +796,8 @@ hipError_t launch_track_reduce(Ctrl *scratch_ctrl, float *partials, float *sums,
     a.seq = 0;
     a.level = 0;
     a.last_iter = 1;
-    a.in_vertex = in_vertex; a.in_normal = in_normal; a.iw = iw; a.ih = ih;
+    a.in_depth = in_depth; a.in_normal = in_normal; a.iw = iw; a.ih = ih;
+    for (int i = 0; i < 4; ++i) a.k[i] = k[i];
     a.ref_vertex = ref_vertex; a.ref_normal = ref_normal; a.rw = rw; a.rh = rh;
     a.dist_threshold = dist_threshold; a.normal_threshold = normal_threshold;
     a.icp_threshold = 0.f;
@@ -1020,7 +1039,13 @@ hipError_t launch_fill_volume(short2 *vol, size_t nvox, hipStream_t s) {
 // and holds planes [zs0, zs1); the march is clipped to z in [zc0, zc1] metres (the whole volume, or the
 // owned slab in the sharded mode).
 // =====================================================================================================
-constexpr int RAY_BATCH = 4;
+constexpr int RAY_BATCH = 4;      // steps one lane keeps in flight for its own ray
+constexpr int RAY_TAIL_MAX = 8;   // at most this many live rays: the wavefront marches them cooperatively
+
+// value of `v` in lane `src`; src is the same for the whole wavefront
+__device__ inline float bcast_lane(float v, int src) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), src));
+}
 
 // Two x-adjacent voxels fetched with one 8-byte load (the volume is only 4-byte aligned at odd x).
 // The empty asm makes the whole 64-bit value live, so the load is not narrowed into two 2-byte loads.
@@ -1147,7 +1172,7 @@ struct VolDev {
 };
 
 template <bool POW2>
-__global__ __launch_bounds__(256) void k_raycast(float4 *__restrict__ vertex, float4 *__restrict__ normal,
+__global__ __launch_bounds__(256, 5) void k_raycast(float4 *__restrict__ vertex, float4 *__restrict__ normal,
                                                  float *__restrict__ ray_t, int w, int h, VolDev<POW2> vol,
                                                  float zc0, float zc1, const Mat4 *__restrict__ view_p,
                                                  float near_plane, float far_plane, float step,
@@ -1156,7 +1181,7 @@ __global__ __launch_bounds__(256) void k_raycast(float4 *__restrict__ vertex, fl
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int x = blockIdx.x * 16 + (wave & 1) * 8 + (lane & 7);
     const int y = blockIdx.y * 16 + (wave >> 1) * 8 + (lane >> 3);
-    if (x >= w || y >= h) return;
+    const bool inside = x < w && y < h;        // lanes outside the image stay as helpers of the tail phase
     const Mat4 view = *view_p;
     const f3 origin = mk3(view.m[3], view.m[7], view.m[11]);
     const f3 direction = rotate(view, mk3((float)x, (float)y, 1.f));
@@ -1173,59 +1198,120 @@ __global__ __launch_bounds__(256) void k_raycast(float4 *__restrict__ vertex, fl
     const float tnear = fmaxf(largest_tmin, near_plane);
     const float tfar = fminf(smallest_tmax, far_plane);
 
-    float4 hit = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (tnear < tfar) {
-        float t = tnear;
-        float stepsize = largestep;
-        float f_t = vol.interp(origin + direction * t);
-        float f_tt = 0;
-        if (f_t > 0) {
-            // The reference loop is  for (; t < tfar; t += stepsize) { f_tt = interp(t); if (f_tt < 0) break;
-            // if (f_tt < 0.8) stepsize = step; f_t = f_tt; }.  The samples of RAY_BATCH consecutive steps are
-            // fetched together (their positions only depend on the current step size) and then consumed in
-            // order; a step-size change discards the rest of the batch.  Same samples, same decisions, one
-            // memory round trip per batch instead of one per step.
-            bool marching = t < tfar;
-            while (marching) {
-                float tk[RAY_BATCH], fk[RAY_BATCH];
-                tk[0] = t;
+    // The reference loop is  for (; t < tfar; t += stepsize) { f_tt = interp(t); if (f_tt < 0) break;
+    // if (f_tt < 0.8) stepsize = step; f_t = f_tt; }.  Same samples and same decisions here, fetched in groups.
+    float t = tnear;
+    float stepsize = largestep;
+    float f_t = 0.f, f_tt = 0.f;
+    bool marching = false;
+    if (inside && tnear < tfar) {
+        f_t = vol.interp(origin + direction * t);
+        marching = f_t > 0;          // already inside the surface: nothing to render (t < tfar holds here)
+    }
+
+    // Phase 1, while many rays of the wavefront are alive: every lane fetches RAY_BATCH consecutive steps of
+    // its own ray together (their positions only depend on the current step size) and consumes them in
+    // order; a step-size change discards the rest of the batch.
+    while (true) {
+        const unsigned long long alive = __ballot(marching);
+        if (alive == 0 || __popcll(alive) <= RAY_TAIL_MAX) break;
+        if (marching) {
+            float tk[RAY_BATCH], fk[RAY_BATCH];
+            tk[0] = t;
 #pragma unroll
-                for (int k = 1; k < RAY_BATCH; ++k) tk[k] = tk[k - 1] + stepsize;
-                typename VolDev<POW2>::Tap taps[RAY_BATCH];
-                typename VolDev<POW2>::TapData raw[RAY_BATCH];
+            for (int k = 1; k < RAY_BATCH; ++k) tk[k] = tk[k - 1] + stepsize;
+            typename VolDev<POW2>::Tap taps[RAY_BATCH];
+            typename VolDev<POW2>::TapData raw[RAY_BATCH];
 #pragma unroll
-                for (int k = 0; k < RAY_BATCH; ++k) {
-                    const float ts = tk[k] < tfar ? tk[k] : t;      // never sample past the far bound
-                    taps[k] = vol.prep(origin + direction * ts);
-                }
-#pragma unroll
-                for (int k = 0; k < RAY_BATCH; ++k) raw[k] = vol.fetch(taps[k]);
-#pragma unroll
-                for (int k = 0; k < RAY_BATCH; ++k) fk[k] = vol.combine(taps[k], raw[k]);
-                bool restart = false;
-#pragma unroll
-                for (int k = 0; k < RAY_BATCH; ++k) {
-                    if (!marching || restart) continue;
-                    if (!(tk[k] < tfar)) { t = tk[k]; marching = false; continue; }
-                    f_tt = fk[k];
-                    t = tk[k];
-                    if (f_tt < 0) { marching = false; continue; }
-                    f_t = f_tt;
-                    if (f_tt < 0.8f && stepsize != step) {
-                        stepsize = step;
-                        t = tk[k] + stepsize;
-                        restart = true;
-                    }
-                }
-                if (marching && !restart) t = tk[RAY_BATCH - 1] + stepsize;
+            for (int k = 0; k < RAY_BATCH; ++k) {
+                const float ts = tk[k] < tfar ? tk[k] : t;      // never sample past the far bound
+                taps[k] = vol.prep(origin + direction * ts);
             }
-            if (f_tt < 0) {
-                t = t + stepsize * f_tt / (f_t - f_tt);
-                const f3 p = origin + direction * t;
-                hit = make_float4(p.x, p.y, p.z, t);
+#pragma unroll
+            for (int k = 0; k < RAY_BATCH; ++k) raw[k] = vol.fetch(taps[k]);
+#pragma unroll
+            for (int k = 0; k < RAY_BATCH; ++k) fk[k] = vol.combine(taps[k], raw[k]);
+            bool restart = false;
+#pragma unroll
+            for (int k = 0; k < RAY_BATCH; ++k) {
+                if (!marching || restart) continue;
+                if (!(tk[k] < tfar)) { t = tk[k]; marching = false; continue; }
+                f_tt = fk[k];
+                t = tk[k];
+                if (f_tt < 0) { marching = false; continue; }
+                f_t = f_tt;
+                if (f_tt < 0.8f && stepsize != step) {
+                    stepsize = step;
+                    t = tk[k] + stepsize;
+                    restart = true;
+                }
             }
+            if (marching && !restart) t = tk[RAY_BATCH - 1] + stepsize;
         }
     }
+
+    // Phase 2, the tail: a few long rays (grazing a surface with the fine step) would otherwise keep the
+    // wavefront alive for dozens of dependent round trips.  The wavefront takes them one at a time and lets
+    // lane k evaluate step k of that ray, 64 steps per round trip; the first lane (in step order) that
+    // meets a loop exit or a step-size change decides, exactly as the sequential loop would.
+    unsigned long long pending = __ballot(marching);
+    while (pending) {
+        const int src = __ffsll((long long)pending) - 1;
+        pending &= pending - 1;
+        const f3 bdir = mk3(bcast_lane(direction.x, src), bcast_lane(direction.y, src), bcast_lane(direction.z, src));
+        const float btfar = bcast_lane(tfar, src);
+        float bt = bcast_lane(t, src), bstep = bcast_lane(stepsize, src), bft = bcast_lane(f_t, src);
+        float r_ftt = 0.f;
+        bool go = true;
+        while (go) {                                            // wave-uniform
+            float tk = bt;                                      // lane k: bt advanced k times, one add at a time
+#pragma unroll 9
+            for (int i = 0; i < 63; ++i) tk = lane > i ? tk + bstep : tk;
+            const bool valid = tk < btfar;
+            const float f = vol.interp(origin + bdir * (valid ? tk : bt));
+            const bool coarse = bstep != step;
+            const unsigned long long m_end = __ballot(!valid);
+            const unsigned long long m_neg = __ballot(valid && f < 0.f);
+            const unsigned long long m_near = coarse ? __ballot(valid && !(f < 0.f) && f < 0.8f) : 0ull;
+            const unsigned long long events = m_end | m_neg | m_near;
+            if (events == 0) {                                  // all 64 steps consumed, none decisive
+                bft = bcast_lane(f, 63);
+                bt = bcast_lane(tk, 63) + bstep;
+                continue;
+            }
+            const int first = __ffsll((long long)events) - 1;
+            const float f_first = bcast_lane(f, first), t_first = bcast_lane(tk, first);
+            if (first > 0) bft = bcast_lane(f, first - 1);      // value of the step before the event
+            if ((m_end >> first) & 1ull) {                      // ran past the far bound: no hit
+                bt = t_first;
+                r_ftt = 0.f;
+                go = false;
+            } else if ((m_neg >> first) & 1ull) {               // zero crossing
+                bt = t_first;
+                r_ftt = f_first;
+                go = false;
+            } else {                                            // first sample below 0.8: switch to the fine step
+                bft = f_first;
+                bstep = step;
+                bt = t_first + step;
+            }
+        }
+        if (lane == src) {
+            t = bt;
+            stepsize = bstep;
+            f_t = bft;
+            f_tt = r_ftt;
+            marching = false;
+        }
+    }
+
+    float4 hit = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (f_tt < 0) {
+        t = t + stepsize * f_tt / (f_t - f_tt);
+        const f3 p = origin + direction * t;
+        hit = make_float4(p.x, p.y, p.z, t);
+    }
+    if (!inside) return;
     const int o = x + y * w;
     if (hit.w > 0.0f) {
         vertex[o] = make_float4(hit.x, hit.y, hit.z, 0.f);

@@ -78,7 +78,7 @@ def lib():
         "kfh_k_bilateral": [vp, vp, i32, i32, vp],
         "kfh_k_half_sample": [vp, vp, i32, i32, f32, vp],
         "kfh_k_vertex_normal": [vp, vp, vp, i32, i32, f32, f32, f32, f32, vp],
-        "kfh_k_track_reduce": [vp, vp, i32, vp, vp, i32, i32, vp, vp, i32, i32, vp, vp, f32, f32, vp],
+        "kfh_k_track_reduce": [vp, vp, i32, vp, vp, vp, i32, i32, vp, vp, i32, i32, vp, vp, f32, f32, vp],
         "kfh_k_update_pose": [vp, vp, vp, vp, f32, vp],
         "kfh_k_integrate": [vp, vp, vp, i32, i32, vp, i32, i32, vp, vp, f32, f32, vp],
         "kfh_k_raycast": [vp, vp, i32, i32, vp, vp, vp, vp, f32, f32, f32, f32, vp],

@@ -143,23 +143,25 @@ def _track_inputs(scene, level, perturb):
     if perturb:
         pose = kf_ref.mat_mul(kf_ref.se3_exp(np.array([0.004, -0.003, 0.002, 0.002, -0.0015, 0.001])), pose)
     view = kf_ref.mat_mul(kf_ref.camera_matrix(k), kf_ref.mat_inverse(ref.pose))
+    k_level = np.array([np.float32(v) / np.float32(1 << level) for v in k], np.float32)
     return (ref.input_vertex(level).copy(), ref.input_normal(level).copy(), ref.model_vertex().copy(),
-            ref.model_normal().copy(), pose, view)
+            ref.model_normal().copy(), pose, view, ref.scaled_depth(level).copy(), k_level)
 
 
 @pytest.mark.parametrize("level,perturb", [(0, False), (0, True), (1, True), (2, True)])
 def test_track_reduce(torch_cuda, L, scene, level, perturb):
     torch = torch_cuda
-    iv, inn, rv, rn, pose, view = _track_inputs(scene, level, perturb)
+    iv, inn, rv, rn, pose, view, depth_l, k_l = _track_inputs(scene, level, perturb)
     ih, iw = iv.shape[:2]
     rh, rw = rv.shape[:2]
     td_want = kf_ref.track(iv, inn, rv, rn, pose, view)
     sums_want = kf_ref.reduce(td_want, iw, ih)
     t = [torch.from_numpy(pad4(a)).cuda() for a in (iv, inn, rv, rn)]
+    d_l = torch.from_numpy(depth_l).cuda()
     sums = torch.empty(32, dtype=torch.float32, device="cuda")
     td = torch.zeros((rh, rw, 8), dtype=torch.float32, device="cuda")
-    native.check(L.kfh_k_track_reduce(vp(sums), vp(td), rw, vp(t[0]), vp(t[1]), iw, ih, vp(t[2]), vp(t[3]), rw, rh,
-                                      hp(m4(pose)), hp(m4(view)), 0.1, 0.8, None))
+    native.check(L.kfh_k_track_reduce(vp(sums), vp(td), rw, vp(d_l), hp(k_l), vp(t[1]), iw, ih, vp(t[2]), vp(t[3]),
+                                      rw, rh, hp(m4(pose)), hp(m4(view)), 0.1, 0.8, None))
     td_got = td.cpu().numpy().view(kf_ref.TRACK_DTYPE).reshape(rh, rw)[:ih, :iw]
     want = td_want[:ih, :iw]
     # data association (result codes) is index work: exact
@@ -202,9 +204,10 @@ def test_track_reduce_no_model(torch_cuda, L):
     view = kf_ref.mat_mul(kf_ref.camera_matrix(k), kf_ref.mat_inverse(pose))
     sums_want = kf_ref.reduce(kf_ref.track(iv, inn, zeros, zeros, pose, view), w, h)
     t = [torch.from_numpy(pad4(a)).cuda() for a in (iv, inn, zeros, zeros)]
+    d_l = torch.from_numpy(raw).cuda()
     sums = torch.empty(32, dtype=torch.float32, device="cuda")
-    native.check(L.kfh_k_track_reduce(vp(sums), None, 0, vp(t[0]), vp(t[1]), w, h, vp(t[2]), vp(t[3]), w, h,
-                                      hp(m4(pose)), hp(m4(view)), 0.1, 0.8, None))
+    native.check(L.kfh_k_track_reduce(vp(sums), None, 0, vp(d_l), hp(np.array(k, np.float32)), vp(t[1]), w, h,
+                                      vp(t[2]), vp(t[3]), w, h, hp(m4(pose)), hp(m4(view)), 0.1, 0.8, None))
     got = sums.cpu().numpy()
     assert np.array_equal(got, sums_want)
     assert got[28] == 0 and got[:28].max() == 0
@@ -223,7 +226,7 @@ def _update_pose_gpu(torch, L, pose, sums, thr=1e-5):
 
 
 def test_update_pose_well_conditioned(torch_cuda, L, scene):
-    iv, inn, rv, rn, pose, view = _track_inputs(scene, 0, True)
+    iv, inn, rv, rn, pose, view, _, _ = _track_inputs(scene, 0, True)
     sums = kf_ref.reduce(kf_ref.track(iv, inn, rv, rn, pose, view), iv.shape[1], iv.shape[0])
     x_want = kf_ref.solve(sums[1:28])
     pose_want, conv_want = kf_ref.update_pose(pose, sums)
