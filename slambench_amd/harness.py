@@ -1,0 +1,77 @@
+"""Driving the SLAMBench-style plugin from Python: the .kfd stream container and the mini-harness runner.
+
+The mini-harness (slambench_amd/plugin/mini_harness.cpp) replays the reference harness' call order around
+libkfusion-hip-library.so; this module writes its input and parses its TSV log, whose layout follows the
+reference's per-frame log (column header at
+icra2018_results/1080/violons_libkfusion-cpp_living_room_traj0_loop.log:36).
+"""
+import os
+import struct
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+PLUGIN_PATH = os.path.join(_HERE, "lib", "libkfusion-hip-library.so")
+MINI_HARNESS_PATH = os.path.join(_HERE, "lib", "kfh_mini_slambench")
+
+# the six symbols the harness resolves with dlsym (reference framework/shared/src/SLAMBenchConfiguration.cpp:107-112)
+PLUGIN_SYMBOLS = ("c_sb_init_slam_system", "c_sb_new_slam_configuration", "c_sb_update_frame",
+                  "c_sb_process_once", "c_sb_clean_slam_system", "c_sb_update_outputs")
+
+
+def write_kfd(path, depth, timestamps, intrinsics_px, depth_scale=0.001):
+    """depth: uint16 [n, h, w]; intrinsics_px: fx, fy, cx, cy in pixels (stored normalised by w, h)."""
+    depth = np.ascontiguousarray(depth, dtype=np.uint16)
+    n, h, w = depth.shape
+    fx, fy, cx, cy = intrinsics_px
+    with open(path, "wb") as f:
+        f.write(b"KFD1")
+        f.write(struct.pack("<III", w, h, n))
+        f.write(struct.pack("<ffff", fx / w, fy / h, cx / w, cy / h))
+        f.write(struct.pack("<f", depth_scale))
+        for i in range(n):
+            f.write(struct.pack("<d", float(timestamps[i])))
+            f.write(depth[i].tobytes())
+
+
+def read_kfd(path):
+    with open(path, "rb") as f:
+        if f.read(4) != b"KFD1":
+            raise ValueError("%s is not a KFD1 file" % path)
+        w, h, n = struct.unpack("<III", f.read(12))
+        intr = struct.unpack("<ffff", f.read(16))
+        (scale,) = struct.unpack("<f", f.read(4))
+        ts = np.empty(n)
+        depth = np.empty((n, h, w), np.uint16)
+        for i in range(n):
+            (ts[i],) = struct.unpack("<d", f.read(8))
+            depth[i] = np.frombuffer(f.read(2 * w * h), np.uint16).reshape(h, w)
+    return depth, ts, (intr[0] * w, intr[1] * h, intr[2] * w, intr[3] * h), scale
+
+
+def parse_log(text):
+    """Returns (properties dict, column names, rows as float array)."""
+    props, cols, rows = {}, [], []
+    section = None
+    for line in text.splitlines():
+        if line.startswith("Properties:"):
+            section = "props"
+        elif line.startswith("Statistics:"):
+            section = "stats"
+        elif section == "props" and ": " in line:
+            k, v = line.split(": ", 1)
+            props[k] = v
+        elif section == "stats" and line.startswith("Frame Number"):
+            cols = line.split("\t")
+        elif section == "stats" and cols and line and line[0].isdigit():
+            rows.append([float(x) for x in line.split("\t")])
+    return props, cols, np.asarray(rows)
+
+
+def run_mini_harness(kfd_path, plugin_args=(), frame_limit=0, library=PLUGIN_PATH, timeout=300):
+    cmd = [MINI_HARNESS_PATH, "-i", kfd_path, "-load", library]
+    if frame_limit:
+        cmd += ["-fl", str(frame_limit)]
+    cmd += list(plugin_args)
+    return subprocess.run(cmd, capture_output=True, text=True, timeout=timeout)

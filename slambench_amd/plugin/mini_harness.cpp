@@ -1,0 +1,179 @@
+// kfh_mini_slambench — a lean stand-in for the `slambench` loader, for machines that cannot build the real one.
+//
+// It replays the call order of the reference harness around a plugin
+// (reference framework/shared/src/SLAMBenchConfiguration.cpp: AddSLAMLibrary :94-133, InitAlgorithms :171-192,
+// ComputeLoopAlgorithm :230-342): dlopen, dlsym of the six mandatory c_sb_* symbols (exit 1 if one is
+// missing), c_sb_new_slam_configuration before the plugin's own options are parsed, c_sb_init_slam_system, then
+// per sensor frame c_sb_update_frame and — once it returns true — BeginFrame, c_sb_process_once,
+// c_sb_update_outputs, EndFrame, one TSV row; finally c_sb_clean_slam_system.  Any `false` from the plugin ends
+// the run with exit code 1, as in the reference.  Three sensor streams (RGB, Depth, Grey) are fed per time
+// step, as the ICL-NUIM / TUM .slam files do, so the plugin's "not my sensor" path is exercised.
+//
+// Input: a .kfd file (this repository's raw depth container, written by slambench_amd/harness.py):
+//   char magic[4] = "KFD1"; uint32 width, height, frames; float fx, fy, cx, cy (normalised by width/height);
+//   float depth_scale (raw unit -> metres); then per frame: double timestamp_s; uint16 depth[height][width].
+#include <SLAMBenchLibraryHelper.h>
+#include <io/SLAMFrame.h>
+#include <io/sensor/CameraSensor.h>
+#include <io/sensor/DepthSensor.h>
+#include <outputs/Output.h>
+#include <values/Value.h>
+
+#include <dlfcn.h>
+
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <iomanip>
+#include <string>
+#include <vector>
+
+namespace sio = slambench::io;
+
+#define LOAD_FUNC2HELPER(handle, lib, f)                                                        \
+    *(void **)(&lib->f) = dlsym(handle, #f);                                                    \
+    if (const char *err = dlerror()) {                                                          \
+        std::fprintf(stderr, "Cannot load symbol '%s': %s\n", #f, err);                         \
+        dlclose(handle);                                                                        \
+        std::exit(1);                                                                           \
+    }
+
+static bool parse_plugin_options(SLAMBenchLibraryHelper *lib, const std::vector<std::string> &args) {
+    for (size_t i = 0; i < args.size(); ++i) {
+        const std::string &a = args[i];
+        Parameter *hit = nullptr;
+        for (Parameter *p : lib->getParameters())
+            if (a == "-" + p->getShortOption() || a == "--" + p->getLongOption()) hit = p;
+        if (!hit) { std::fprintf(stderr, "unknown option %s\n", a.c_str()); return false; }
+        if (hit->requiresValue()) {
+            if (i + 1 >= args.size()) { std::fprintf(stderr, "option %s needs a value\n", a.c_str()); return false; }
+            hit->setValue(args[++i].c_str());
+        } else {
+            hit->setValue(nullptr);
+        }
+    }
+    return true;
+}
+
+int main(int argc, char **argv) {
+    std::string input, library, log_file;
+    int frame_limit = 0;
+    std::vector<std::string> plugin_args;
+    for (int i = 1; i < argc; ++i) {
+        const std::string a = argv[i];
+        auto need = [&](const char *what) { if (i + 1 >= argc) { std::fprintf(stderr, "%s needs a value\n", what); std::exit(1); } return std::string(argv[++i]); };
+        if (a == "-i" || a == "--input") input = need("-i");
+        else if (a == "-load" || a == "--load-library") library = need("-load");
+        else if (a == "-o" || a == "--log-file") log_file = need("-o");
+        else if (a == "-fl" || a == "--frame-limit") frame_limit = std::atoi(need("-fl").c_str());
+        else plugin_args.push_back(a);
+    }
+    if (input.empty() || library.empty()) {
+        std::fprintf(stderr, "usage: %s -i stream.kfd -load libkfusion-hip-library.so [-fl N] [-o log] [plugin options]\n", argv[0]);
+        return 1;
+    }
+
+    // ---- input file -> sensors ----
+    std::ifstream in(input, std::ios::binary);
+    char magic[4];
+    uint32_t w = 0, h = 0, n = 0;
+    float intr[4], depth_scale = 0.f;
+    in.read(magic, 4);
+    in.read((char *)&w, 4); in.read((char *)&h, 4); in.read((char *)&n, 4);
+    in.read((char *)intr, 16); in.read((char *)&depth_scale, 4);
+    if (!in || std::memcmp(magic, "KFD1", 4) != 0) { std::fprintf(stderr, "%s is not a KFD1 file\n", input.c_str()); return 1; }
+
+    sio::InputInterface interface;
+    auto *rgb = new sio::CameraSensor("RGB");
+    rgb->Width = w; rgb->Height = h; rgb->PixelFormat = sio::pixelformat::RGB_III_888;
+    auto *depth = new sio::DepthSensor("Depth");
+    depth->Width = w; depth->Height = h; depth->PixelFormat = sio::pixelformat::D_I_16;
+    depth->DisparityParams[0] = depth_scale; depth->DisparityParams[1] = 0.f;
+    auto *grey = new sio::CameraSensor("Grey");
+    grey->Width = w; grey->Height = h; grey->PixelFormat = sio::pixelformat::G_I_8;
+    for (sio::CameraSensor *s : {rgb, (sio::CameraSensor *)depth, grey}) {
+        std::memcpy(s->Intrinsics, intr, sizeof(intr));
+        interface.GetSensors().AddSensor(s);
+    }
+
+    // ---- AddSLAMLibrary ----
+    void *handle = dlopen(library.c_str(), RTLD_LAZY);
+    if (!handle) { std::fprintf(stderr, "Cannot open library: %s\n", dlerror()); return 1; }
+    dlerror();
+    size_t start = library.find_last_of('/') == std::string::npos ? 0 : library.find_last_of('/') + 1;
+    std::string libname = library.substr(start);
+    if (libname.compare(0, 3, "lib") == 0) libname = libname.substr(3);
+    libname = libname.substr(0, libname.find('-'));
+    auto *lib = new SLAMBenchLibraryHelper("", libname, std::cerr, &interface);
+    LOAD_FUNC2HELPER(handle, lib, c_sb_init_slam_system);
+    LOAD_FUNC2HELPER(handle, lib, c_sb_new_slam_configuration);
+    LOAD_FUNC2HELPER(handle, lib, c_sb_update_frame);
+    LOAD_FUNC2HELPER(handle, lib, c_sb_process_once);
+    LOAD_FUNC2HELPER(handle, lib, c_sb_clean_slam_system);
+    LOAD_FUNC2HELPER(handle, lib, c_sb_update_outputs);
+    if (dlsym(handle, "_Z13sb_relocalizeP22SLAMBenchLibraryHelper")) {
+        *(void **)(&lib->c_sb_relocalize) = dlsym(handle, "c_sb_relocalize");
+    } else {
+        lib->c_sb_relocalize = lib->c_sb_process_once;
+    }
+    dlerror();
+    if (!lib->c_sb_new_slam_configuration(lib)) { std::fprintf(stderr, "Configuration construction failed.\n"); return 1; }
+    if (!parse_plugin_options(lib, plugin_args)) return 1;
+
+    std::ostream *log = &std::cout;
+    std::ofstream log_stream;
+    if (!log_file.empty()) { log_stream.open(log_file); log = &log_stream; }
+    *log << "Properties:\n=================\n\n";
+    *log << "frame-limit: " << frame_limit << "\ninput: " << input << "\nload-library: " << library << "\n";
+    *log << "Depth-intrinsics-parameters: " << intr[0] << "," << intr[1] << "," << intr[2] << "," << intr[3] << "\n";
+    *log << "Depth-disparity-params: " << depth_scale << ",0\n";
+    for (Parameter *p : lib->getParameters()) *log << p->getLongOption() << ": " << p->getStrValue() << "\n";
+
+    // ---- InitAlgorithms ----
+    if (!lib->c_sb_init_slam_system(lib)) { std::fprintf(stderr, "Algorithm initialization failed.\n"); return 1; }
+    auto *trajectory = lib->GetOutputManager().GetMainOutput(slambench::values::VT_POSE);
+    if (!trajectory) { std::fprintf(stderr, "Algo does not provide a main pose output\n"); return 1; }
+    trajectory->SetActive(true);
+
+    *log << "\nStatistics:\n=================\n\nFrame Number\tTimestamp\tDuration_Frame";
+    for (auto *p : lib->GetMetricManager().GetPhases()) *log << "\tDuration_" << p->GetName();
+    *log << "\tX\tY\tZ\n";
+    *log << std::fixed << std::setprecision(10);
+
+    // ---- ComputeLoopAlgorithm ----
+    std::vector<uint16_t> depth_buf((size_t)w * h);
+    std::vector<unsigned char> dummy(4, 0);
+    unsigned processed = 0;
+    for (uint32_t f = 0; f < n; ++f) {
+        double ts_s = 0.0;
+        in.read((char *)&ts_s, 8);
+        in.read((char *)depth_buf.data(), depth_buf.size() * 2);
+        if (!in) { std::fprintf(stderr, "truncated input at frame %u\n", f); return 1; }
+        const slambench::TimeStamp ts = slambench::TimeStamp::get((uint32_t)ts_s, (uint32_t)((ts_s - (uint32_t)ts_s) * 1e9 + 0.5));
+        sio::SLAMInMemoryFrame frames[3];
+        frames[0].FrameSensor = rgb;   frames[0].Data = dummy.data();     frames[0].Size = 0;
+        frames[1].FrameSensor = depth; frames[1].Data = depth_buf.data(); frames[1].Size = depth_buf.size() * 2;
+        frames[2].FrameSensor = grey;  frames[2].Data = dummy.data();     frames[2].Size = 0;
+        for (auto &fr : frames) {
+            fr.Timestamp = ts;
+            const bool ongoing = !lib->c_sb_update_frame(lib, &fr);
+            if (ongoing) continue;
+            lib->GetMetricManager().BeginFrame();
+            if (!lib->c_sb_process_once(lib)) { std::fprintf(stderr, "Error after lib->c_sb_process_once.\n"); return 1; }
+            slambench::TimeStamp out_ts = ts;
+            if (!lib->c_sb_update_outputs(lib, &out_ts)) { std::fprintf(stderr, "Failed to get outputs\n"); return 1; }
+            lib->GetMetricManager().EndFrame();
+            ++processed;
+            auto *out = static_cast<slambench::outputs::Output *>(trajectory);
+            const auto &pose = static_cast<const slambench::values::PoseValue *>(out->GetMostRecentValue().second)->GetValue();
+            *log << processed << "\t" << ts.ToS() << "\t" << lib->GetMetricManager().LastFrameDuration();
+            for (auto *p : lib->GetMetricManager().GetPhases())
+                *log << "\t" << lib->GetMetricManager().LastPhaseDurations().at(p->GetName());
+            *log << "\t" << pose(0, 3) << "\t" << pose(1, 3) << "\t" << pose(2, 3) << "\n";
+        }
+        if (frame_limit > 0 && processed >= (unsigned)frame_limit) break;
+    }
+    if (!lib->c_sb_clean_slam_system()) { std::fprintf(stderr, "Algorithm cleaning failed.\n"); return 1; }
+    delete lib;
+    return 0;
+}

@@ -1,0 +1,173 @@
+"""CPU suite, part 2: host logic, the C ABI surface and the plugin boundary (no compute without a GPU)."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from slambench_amd import harness, native, synth
+from slambench_amd.config import KFusionConfig, KfhConfig
+from slambench_amd.metrics import align_umeyama, ate, umeyama
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _has_gpu():
+    n = C.c_int(0)
+    native.lib().kfh_device_count(C.byref(n))
+    return n.value > 0
+
+
+# ------------------------------------------------------------------ C ABI surface
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "kfusion_hip.h")).read()
+    declared = set(re.findall(r"^(?:int|const char \*)\s*\*?(kfh_\w+)\s*\(", header, re.M))
+    assert len(declared) >= 30
+    assert declared == set(native.EXPORTED_SYMBOLS)
+    L = C.CDLL(native.LIB_PATH)
+    for name in declared:
+        assert hasattr(L, name), name
+    assert native.lib().kfh_version() >= 100
+
+
+def test_config_struct_layout_matches_header():
+    # 3 ints, 5 floats, 3+3+3 words, 2 floats, 3 ints, 2 ints, 1 int, 2 ints
+    assert C.sizeof(KfhConfig) == 4 * (3 + 5 + 9 + 2 + 3 + 2 + 1 + 2)
+    from oracle import kf_ref
+    assert [f[0] for f in KfhConfig._fields_] == [f[0] for f in kf_ref.Config._fields_]
+    assert C.sizeof(native.FrameStatus) == 4 * (4 + 16 + 32 + 2)
+
+
+def test_invalid_arguments_are_rejected_before_any_device_work():
+    L = native.lib()
+    ctx = C.c_void_p()
+    for mutate, text in [(lambda c: setattr(c, "compute_size_ratio", 3), b"compute_size_ratio"),
+                         (lambda c: setattr(c, "mu", 0.0), b"mu must be positive"),
+                         (lambda c: setattr(c, "slab_z1", 10 ** 6), b"slab"),
+                         (lambda c: setattr(c, "input_width", 642), b"divisible")]:
+        c = KFusionConfig().to_c()
+        mutate(c)
+        assert L.kfh_create(C.byref(c), C.byref(ctx)) == 1
+        assert text in L.kfh_last_error()
+        assert not ctx.value
+    assert L.kfh_create(None, C.byref(ctx)) == 1
+    assert L.kfh_sync(None) == 1 and L.kfh_get_pose(None, None) == 1
+    assert L.kfh_k_half_sample(None, None, 8, 8, 0.3, None) == 1
+
+
+def test_create_without_device_reports_no_device():
+    if _has_gpu():
+        pytest.skip("a HIP device is visible")
+    c = KFusionConfig().to_c()
+    ctx = C.c_void_p()
+    assert native.lib().kfh_create(C.byref(c), C.byref(ctx)) == 4
+    assert b"no HIP device" in native.lib().kfh_last_error()
+    with pytest.raises(native.KfhError):
+        from slambench_amd.kfusion import KFusion
+        KFusion(KFusionConfig())
+
+
+# ------------------------------------------------------------------ configuration
+def test_config_validation_and_derived_values():
+    cfg = KFusionConfig(compute_size_ratio=2)
+    assert cfg.compute_size == (320, 240)
+    assert cfg.camera == pytest.approx((240.6, 240.0, 159.75, 119.75))
+    c = cfg.to_c()
+    assert (c.slab_z0, c.slab_z1) == (0, 256) and c.depth_divisor == 1000.0
+    for bad in [dict(compute_size_ratio=3), dict(volume_resolution=(0, 1, 1)), dict(integration_rate=0),
+                dict(input_size=(642, 480)), dict(slab=(4, 2)), dict(pyramid=(1, 2))]:
+        with pytest.raises(ValueError):
+            KFusionConfig(**bad).to_c()
+    assert KFusionConfig(volume_resolution=(64, 64, 64), slab=(16, 32)).to_c().slab_z1 == 32
+
+
+# ------------------------------------------------------------------ synthetic stream
+def test_synthetic_stream_properties():
+    depth, gt, ts = synth.make_sequence(5, seed=3, size=(160, 120), intrinsics=(120.3, 120.0, 79.875, 59.875))
+    depth2, gt2, _ = synth.make_sequence(5, seed=3, size=(160, 120), intrinsics=(120.3, 120.0, 79.875, 59.875))
+    assert np.array_equal(depth, depth2) and np.array_equal(gt, gt2)
+    assert depth.dtype == np.uint16 and depth.shape == (5, 120, 160)
+    assert 500 < depth.min() and depth.max() < 4000          # the whole room is inside KinectFusion's range
+    assert np.array_equal(gt[0], np.array([[1, 0, 0, 4], [0, 1, 0, 4], [0, 0, 1, 4], [0, 0, 0, 1]], float))
+    assert np.linalg.norm(gt[3][:3, 3] - gt[0][:3, 3]) < 2e-3   # the camera starts at rest
+    noisy, _, _ = synth.make_sequence(2, seed=3, size=(160, 120), noise=True)
+    assert 0.005 < (noisy == 0).mean() < 0.05                   # about 2 % holes
+    other, _, _ = synth.make_sequence(2, seed=4, size=(160, 120))
+    assert not np.array_equal(other[:2], depth[:2])
+
+
+# ------------------------------------------------------------------ ATE / alignment
+def test_umeyama_recovers_a_similarity_transform():
+    rng = np.random.default_rng(0)
+    src = rng.normal(size=(3, 40))
+    ang = 0.7
+    R = np.array([[np.cos(ang), -np.sin(ang), 0], [np.sin(ang), np.cos(ang), 0], [0, 0, 1]])
+    dst = 1.3 * R @ src + np.array([[0.5], [-2.0], [1.0]])
+    T = umeyama(src, dst, True)
+    np.testing.assert_allclose(T[:3, :3], 1.3 * R, atol=1e-9)
+    np.testing.assert_allclose(T[:3, 3], [0.5, -2.0, 1.0], atol=1e-9)
+
+
+def test_ate_definition():
+    n = 20
+    gt = synth.lissajous_trajectory(n, amp=0.5, period_s=1.0)
+    ts = np.arange(n) / 30.0
+    assert ate(gt, gt, ts, ts)["rmse"] < 1e-12
+    # a rigidly displaced estimate aligns back to zero error (Umeyama), an unaligned one does not
+    shifted = gt.copy()
+    shifted[:, :3, 3] += [0.1, -0.2, 0.3]
+    assert ate(shifted, gt, ts, ts)["rmse"] < 1e-9
+    assert ate(shifted, gt, ts, ts, align=False)["max"] == pytest.approx(np.sqrt(0.14))
+    # one outlier frame: mean / max / rmse as defined in the reference's ATEMetric
+    est = gt.copy()
+    est[7, 0, 3] += 0.3
+    a = ate(est, gt, ts, ts, align=False)
+    assert a["max"] == pytest.approx(0.3) and a["mean"] == pytest.approx(0.3 / n)
+    assert a["rmse"] == pytest.approx(0.3 / np.sqrt(n)) and a["last"] == 0.0
+    # ground truth at a different rate: each estimate meets the first ground-truth pose that is not earlier
+    a2 = ate(gt[::2], gt, ts[::2], ts, align=False)
+    assert a2["rmse"] < 1e-12
+    assert align_umeyama(gt[:2], gt[:2], ts[:2], ts[:2]).shape == (4, 4)
+
+
+# ------------------------------------------------------------------ plugin boundary
+def test_plugin_exports_the_six_entry_points_and_no_relocalize():
+    lib = C.CDLL(harness.PLUGIN_PATH)
+    for name in harness.PLUGIN_SYMBOLS:
+        assert hasattr(lib, name), name
+    # the harness probes for the mangled C++ symbol and otherwise aliases relocalisation to process_once
+    assert not hasattr(lib, "c_sb_relocalize")
+    assert not hasattr(lib, "_Z13sb_relocalizeP22SLAMBenchLibraryHelper")
+    out = subprocess.run(["nm", "-D", "--defined-only", harness.PLUGIN_PATH], capture_output=True, text=True).stdout
+    assert "_Z15sb_process_onceP22SLAMBenchLibraryHelper" in out      # same mangled names as a reference plugin
+
+
+def test_kfd_round_trip_and_log_parser(tmp_path):
+    depth, gt, ts = synth.make_sequence(3, seed=1, size=(64, 48), intrinsics=(48.12, 48.0, 31.95, 23.95))
+    path = str(tmp_path / "s.kfd")
+    harness.write_kfd(path, depth, ts, (48.12, 48.0, 31.95, 23.95), 0.001)
+    d2, t2, intr, scale = harness.read_kfd(path)
+    assert np.array_equal(d2, depth) and np.allclose(t2, ts)
+    assert intr == pytest.approx((48.12, 48.0, 31.95, 23.95), rel=1e-6) and scale == pytest.approx(0.001)
+    props, cols, rows = harness.parse_log(
+        "Properties:\n=================\n\nmu: 0.1\n\nStatistics:\n=================\n\n"
+        "Frame Number\tTimestamp\tX\n1\t0.0000000000\t4.0000000000\n2\t0.0333333333\t4.0010000000\n")
+    assert props == {"mu": "0.1"} and cols == ["Frame Number", "Timestamp", "X"] and rows.shape == (2, 3)
+
+
+def test_mini_harness_exit_codes_without_a_gpu(tmp_path):
+    depth, gt, ts = synth.make_sequence(2, seed=1, size=(64, 48), intrinsics=(48.12, 48.0, 31.95, 23.95))
+    path = str(tmp_path / "s.kfd")
+    harness.write_kfd(path, depth, ts, (48.12, 48.0, 31.95, 23.95))
+    # a library without the plugin symbols is refused with exit code 1, like the reference loader
+    r = harness.run_mini_harness(path, library=native.LIB_PATH)
+    assert r.returncode == 1 and "Cannot load symbol" in r.stderr
+    r = harness.run_mini_harness(path, ["--bogus"])
+    assert r.returncode == 1 and "unknown option" in r.stderr
+    if not _has_gpu():
+        # sb_init_slam_system returns false when no device is present -> "exit(1)" path of the harness
+        r = harness.run_mini_harness(path, ["-c", "1", "-v", "32"])
+        assert r.returncode == 1 and "initialization failed" in r.stderr
+        assert "compute-size-ratio: 1" in r.stdout and "volume-resolution: 32,32,32" in r.stdout

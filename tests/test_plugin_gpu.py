@@ -1,0 +1,53 @@
+"""The SLAMBench plugin boundary on a GPU: mini-harness -> c_sb_* -> C ABI must reproduce the direct pipeline."""
+import numpy as np
+import pytest
+
+from slambench_amd import harness, synth
+from slambench_amd.config import KFusionConfig
+from slambench_amd.kfusion import KFusion
+
+pytestmark = pytest.mark.gpu
+
+
+def test_mini_harness_matches_direct_pipeline(torch_cuda, tmp_path):
+    n = 12
+    intr = (481.2, 480.0, 319.5, 239.5)
+    depth, gt, ts = synth.make_sequence(n, seed=1, intrinsics=intr)
+    path = str(tmp_path / "stream.kfd")
+    harness.write_kfd(path, depth, ts, intr, 0.001)
+    r = harness.run_mini_harness(path, ["--compute-size-ratio", "4", "--volume-resolution", "64,64,64", "-m", "0.1"])
+    assert r.returncode == 0, r.stderr
+    props, cols, rows = harness.parse_log(r.stdout)
+    assert props["compute-size-ratio"] == "4" and props["volume-resolution"] == "64,64,64"
+    assert props["integration-rate"] == "2" and props["pyramid-level1"] == "10"
+    assert cols[:3] == ["Frame Number", "Timestamp", "Duration_Frame"]
+    assert cols[3:8] == ["Duration_Preprocessing", "Duration_Tracking", "Duration_Integration",
+                         "Duration_Raycasting", "Duration_Render"]
+    assert rows.shape == (n, 11)
+    # same frames through the Python mirror of the Kfusion class.  The plugin rebuilds pixel intrinsics from
+    # the normalised values the harness stores (fx / W * W), as the reference plugin does.
+    w, h = 640, 480
+    intr_rt = tuple(np.float32(v / s) * np.float32(s) for v, s in zip(intr, (w, h, w, h)))
+    kf = KFusion(KFusionConfig(intrinsics=tuple(float(v) for v in intr_rt), compute_size_ratio=4,
+                               volume_resolution=(64, 64, 64)))
+    for i in range(n):
+        kf.process_frame(depth[i])
+    traj = kf.trajectory()
+    np.testing.assert_allclose(rows[:, 8:11], traj[:, :3, 3], rtol=0, atol=1e-6)
+    assert np.allclose(rows[:4, 8:11], 4.0)            # pose frozen until the model exists
+    kf.close()
+
+
+def test_frame_limit_and_bad_option(torch_cuda, tmp_path):
+    depth, gt, ts = synth.make_sequence(6, seed=2)
+    path = str(tmp_path / "s.kfd")
+    harness.write_kfd(path, depth, ts, (481.2, 480.0, 319.5, 239.5))
+    r = harness.run_mini_harness(path, ["-c", "8", "-v", "32"], frame_limit=3)
+    assert r.returncode == 0, r.stderr
+    _, _, rows = harness.parse_log(r.stdout)
+    assert rows.shape[0] == 3
+    r = harness.run_mini_harness(path, ["--no-such-option", "1"])
+    assert r.returncode == 1 and "unknown option" in r.stderr
+    # an invalid configuration makes sb_init_slam_system return false -> the harness exits with 1
+    r = harness.run_mini_harness(path, ["-c", "3"])
+    assert r.returncode == 1 and "initialization failed" in r.stderr
