@@ -37,6 +37,10 @@ def parse_args():
     ap.add_argument("--cpu-frames", type=int, default=12, help="frames of the CPU baseline sample (0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--mode", choices=["replicas", "zslab"], default="replicas",
+                    help="N>1: one independent sequence per GPU (default), or ONE sequence whose volume is "
+                         "sharded into z-slabs across the GPUs")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (gloo for a one-GPU rehearsal)")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "integrate_traffic.json"),
                     help="HBM bytes per integrate launch from the committed rocprofv3 PMC passes")
     return ap.parse_args()
@@ -81,21 +85,34 @@ def main():
     from slambench_amd.metrics import ate
 
     assert torch.cuda.is_available(), "bench.py needs a HIP device"
-    torch.cuda.set_device(local_rank)
+    device_index = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(device_index)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device_index))
+        else:
+            dist.init_process_group(a.backend)
+    zslab = a.mode == "zslab" and world > 1
 
     V = a.volume
     cfg = KFusionConfig(input_size=(640, 480), intrinsics=TUM_FR1_DEPTH_INTRINSICS, compute_size_ratio=a.csr,
                         volume_resolution=(V, V, V))
     total = a.steps + a.warmup
     n_unique = max(8, min(a.unique_frames, total))
-    depth, gt, ts = synth.make_sequence(n_unique, seed=1 + rank, intrinsics=TUM_FR1_DEPTH_INTRINSICS, noise=True)
+    seed = 1 if zslab else 1 + rank          # sharded: every rank sees the same frames (broadcast input)
+    depth, gt, ts = synth.make_sequence(n_unique, seed=seed, intrinsics=TUM_FR1_DEPTH_INTRINSICS, noise=True)
     order = ping_pong(n_unique, total)
     d_depth = torch.from_numpy(depth.view(np.int16)).cuda()      # every frame resident in HBM
     frame_ptrs = [int(d_depth[i].data_ptr()) for i in range(n_unique)]
 
-    kf = KFusion(cfg)
+    if zslab:
+        from slambench_amd.sharded import SlabKFusion
+        sharded = SlabKFusion(cfg, rank, world, dist, torch)
+        kf = sharded.kf
+        step = sharded.process_frame
+    else:
+        kf = KFusion(cfg)
+        step = kf.process_frame
     kf.set_timing(2)     # two HIP events per frame around the integration phase, on the pipeline's stream
 
     def barrier():
@@ -105,16 +122,16 @@ def main():
         kf.sync()
 
     for i in range(a.warmup):
-        kf.process_frame(frame_ptrs[order[i]])
+        step(frame_ptrs[order[i]])
     barrier()
     t0 = time.perf_counter()
     for i in range(a.warmup, total):
-        kf.process_frame(frame_ptrs[order[i]])
+        step(frame_ptrs[order[i]])
     kf.sync()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if a.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
         dist.barrier()
@@ -130,7 +147,9 @@ def main():
             integ_ms.append(float(kf.phase_ms(f)[2]))
     integ_ms = np.asarray(integ_ms)
     t_int = float(integ_ms.mean()) * 1e-3 if integ_ms.size else float("nan")
-    alg_bytes = 8.0 * V ** 3                       # 4 B read + 4 B written per voxel, whole volume per launch
+    zs = kf.cfg.slab if kf.cfg.slab != (0, 0) else (0, V)
+    planes = min(zs[1] + 2, V) - max(zs[0] - 2, 0) if zslab else V
+    alg_bytes = 8.0 * V * V * planes               # 4 B read + 4 B written per voxel of this device's planes
     achieved = alg_bytes / t_int / 1e9 if integ_ms.size else float("nan")
 
     # accuracy on the forward part of the stream (ground truth is known for the synthetic camera)
@@ -151,7 +170,7 @@ def main():
                 traffic = None
         result = {
             "metric": "KFusion frames/s @640x480 512^3 TSDF; integrate GVox/s; ATE delta vs ref",
-            "value": world * a.steps / elapsed,
+            "value": (1 if zslab else world) * a.steps / elapsed,
             "unit": "frames/s",
             "n_gpus": world,
             "steps": a.steps,
@@ -166,9 +185,11 @@ def main():
                 "workload": "KFusion 640x480 depth (TUM fr1 intrinsics), %d^3 TSDF over 8 m, ICP 10/5/4, "
                             "integration-rate 2, synthetic room stream (configs[1])" % V,
                 "compute_size": "%dx%d" % cfg.compute_size, "volume": V,
-                "parallelism": "1 sequence per GPU (replicas, no collective)" if world > 1 else "single GPU",
+                "parallelism": ("one sequence, volume in %d z-slabs, raycast segments all-gathered (%s)" % (world, a.backend)
+                                if zslab else "1 sequence per GPU (replicas, no collective)" if world > 1
+                                else "single GPU"),
             },
-            "integrate_gvox_per_s": (V ** 3 / t_int / 1e9) if integ_ms.size else None,
+            "integrate_gvox_per_s": (V * V * planes / t_int / 1e9) if integ_ms.size else None,
             "integrate_ms": t_int * 1e3 if integ_ms.size else None,
             "tracked_fraction": tracked / max(1, total - first),
             "ate_rmse_m": ate_hip,

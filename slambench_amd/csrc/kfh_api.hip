@@ -339,7 +339,10 @@ int kfh_integrate(kfh_context *c) {
                                  &c->d_ctrl->inv_pose, camera_matrix(c->k[0], c->k[1], c->k[2], c->k[3]),
                                  c->cfg.mu, MAX_WEIGHT, &c->d_ctrl->integrate_gate, c->stream));
     }
-    if (c->timing) KFH_HIP(hipEventRecord(c->ev[c->frame % KFH_TIMING_RING][3], c->stream));
+    if (c->timing) {
+        KFH_HIP(hipEventRecord(c->ev[c->frame % KFH_TIMING_RING][3], c->stream));
+        if (c->timing == 2 && c->timed_first < 0) c->timed_first = c->frame;
+    }
     return KFH_OK;
 }
 
@@ -358,8 +361,10 @@ int kfh_raycast(kfh_context *c) {
                                c->cfg.vol_dim, 0, c->cfg.vol_res[2], &c->d_ctrl->view, NEAR_PLANE, FAR_PLANE,
                                raycast_step(c->cfg), 0.75f * c->cfg.mu, c->stream));
     }
-    if (c->timing == 1) KFH_HIP(hipEventRecord(c->ev[c->frame % KFH_TIMING_RING][4], c->stream));
-    if (c->timing && c->timed_first < 0) c->timed_first = c->frame;
+    if (c->timing == 1) {
+        KFH_HIP(hipEventRecord(c->ev[c->frame % KFH_TIMING_RING][4], c->stream));
+        if (c->timed_first < 0) c->timed_first = c->frame;
+    }
     return KFH_OK;
 }
 

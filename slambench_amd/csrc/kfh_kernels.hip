@@ -1346,8 +1346,10 @@ static hipError_t launch_raycast_t(float4 *vertex, float4 *normal, float *ray_t,
         // sharded: planes [z0-2, z1+2) are stored, the march is clipped to the owned z range
         v.zs0 = z0 - 2 > 0 ? z0 - 2 : 0;
         v.zs1 = z1 + 2 < res[2] ? z1 + 2 : res[2];
+        // one voxel past the owned range (the halo holds it), so that a zero crossing between the last
+        // sample of this slab and the first of the next is still seen here
         zc0 = (float)z0 * (dim[2] / (float)res[2]);
-        zc1 = (float)z1 * (dim[2] / (float)res[2]);
+        zc1 = (float)(z1 < res[2] ? z1 + 1 : z1) * (dim[2] / (float)res[2]);
     }
     const dim3 grid((w + 15) / 16, (h + 15) / 16);
     hipLaunchKernelGGL(k_raycast<POW2>, grid, dim3(256), 0, s, vertex, normal, ray_t, w, h, v, zc0, zc1, view,

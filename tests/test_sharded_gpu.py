@@ -1,0 +1,79 @@
+"""Z-slab sharding on one GPU: two slab contexts in one process against the single full-volume context.
+
+The exchange step (all-gather of the per-slab ray segments) is replaced by a local stack, so this exercises
+kfh_raycast_slab / kfh_composite_slabs and the redundant-halo integration through the C ABI; the collective
+itself is covered by the gloo test in tests/test_distributed_cpu.py.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from slambench_amd import native, synth
+from slambench_amd.config import KFusionConfig
+from slambench_amd.kfusion import KFusion
+from slambench_amd.sharded import composite_numpy, slab_bounds
+
+pytestmark = pytest.mark.gpu
+
+
+def test_two_slabs_reproduce_the_full_volume(torch_cuda):
+    torch = torch_cuda
+    V, n = 128, 16
+    base = dict(compute_size_ratio=2, volume_resolution=(V, V, V))
+    full = KFusion(KFusionConfig(**base))
+    slabs = [KFusion(KFusionConfig(**base, slab=slab_bounds(V, 2, r))) for r in range(2)]
+    depth, gt, ts = synth.make_sequence(n, seed=1)
+    L = native.lib()
+    w, h = full.width, full.height
+    for i in range(n):
+        full.process_frame(depth[i])
+        for kf in slabs:
+            kf.set_depth(depth[i])
+            kf.preprocessing()
+            kf.tracking()
+            kf.integration()
+            native.check(L.kfh_raycast_slab(kf._ctx))
+        if i > 2:
+            t = torch.from_numpy(np.stack([kf.download(native.BUF_RAY_T) for kf in slabs])).cuda()
+            v = torch.from_numpy(np.stack([kf.download(native.BUF_MODEL_VERTEX) for kf in slabs])).cuda()
+            nm = torch.from_numpy(np.stack([kf.download(native.BUF_MODEL_NORMAL) for kf in slabs])).cuda()
+            for kf in slabs:
+                native.check(L.kfh_composite_slabs(kf._ctx, C.c_void_p(t.data_ptr()), C.c_void_p(v.data_ptr()),
+                                                   C.c_void_p(nm.data_ptr()), 2))
+            if i == 3:
+                # device composite == host restatement of the min-t rule
+                tc, vc, nc = composite_numpy(t.cpu().numpy(), v.cpu().numpy(), nm.cpu().numpy())
+                assert np.array_equal(slabs[0].download(native.BUF_MODEL_VERTEX), vc)
+                assert np.array_equal(slabs[0].download(native.BUF_RAY_T), tc)
+                got_n = slabs[1].download(native.BUF_MODEL_NORMAL)
+                assert np.array_equal(got_n[..., 0], nc[..., 0])
+                # first raycast: same volume, same pose -> the composited map is the single-device map except
+                # where a ray's step state restarts at the slab boundary
+                v_full = full.download(native.BUF_MODEL_VERTEX)[..., :3]
+                hit_full = full.download(native.BUF_MODEL_NORMAL)[..., 0] != -2
+                hit_sh = nc[..., 0] != -2
+                assert (hit_full == hit_sh).mean() > 0.995
+                both = hit_full & hit_sh
+                d = np.linalg.norm(v_full[both] - vc[..., :3][both], axis=1)
+                assert (d == 0).mean() > 0.85          # most rays never change slab before they hit
+                assert d.max() < 2 * 8.0 / V           # the rest moves by less than two voxels
+        for kf in slabs:
+            kf.end_frame()
+        if i == 3:
+            # pose still the initial one: the owned planes of each slab are bit-identical to the full volume
+            vol = full.download(native.BUF_VOLUME)
+            for r, kf in enumerate(slabs):
+                z0, z1 = slab_bounds(V, 2, r)
+                zs0 = max(z0 - 2, 0)
+                part = kf.download(native.BUF_VOLUME)
+                assert part.shape[0] == min(z1 + 2, V) - zs0
+                assert np.array_equal(part[z0 - zs0:z1 - zs0], vol[z0:z1])
+    # both slab ranks hold the same trajectory, within 1 mm of the single-device run
+    tr_full = full.trajectory()
+    tr = [kf.trajectory() for kf in slabs]
+    assert np.array_equal(tr[0], tr[1])
+    assert np.abs(tr[0][:, :3, 3] - tr_full[:, :3, 3]).max() < 1e-3
+    assert all(full.status(f)["tracked"] == slabs[0].status(f)["tracked"] for f in range(n))
+    for kf in slabs + [full]:
+        kf.close()
