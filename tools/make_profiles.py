@@ -1,0 +1,88 @@
+"""Condense rocprofv3 output directories (merged back under gpurun_out/) into the tracked files of profiles/.
+
+usage: make_profiles.py TAG FRAMES KERNEL_TRACE_DIR FETCH_PMC_DIR WRITE_PMC_DIR [VOLUME]
+
+Writes profiles/TAG_kernel_stats.csv (rocprofv3's own per-kernel statistics, verbatim),
+profiles/TAG_kernel_summary.txt, profiles/TAG_pmc_per_kernel.json (mean counter value per launch and kernel)
+and profiles/integrate_traffic.json (HBM bytes per k_integrate launch, which bench.py reports as
+roofline.traffic).  On gfx950 FETCH_SIZE counts 64-byte units for requests that move 128 bytes, so the
+byte figure is 2 x FETCH_SIZE KiB; WRITE_SIZE is exact.  Both corrections were checked against a launch
+whose traffic is known (tools/dense_integrate.py: every voxel read and written once).
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def short(name):
+    return name.split("(")[0].replace("void ", "").replace("kfh::", "")
+
+
+def kernel_summary(d, frames):
+    f = glob.glob(d + "/**/*kernel_stats.csv", recursive=True)[0]
+    rows = list(csv.DictReader(open(f)))
+    tot = sum(int(r["TotalDurationNs"]) for r in rows)
+    out = ["%-28s %7s %10s %10s %6s %9s %9s" % ("kernel", "calls", "total_ms", "avg_us", "%", "min_us", "max_us")]
+    for r in rows:
+        out.append("%-28s %7s %10.2f %10.1f %6.1f %9.1f %9.1f" % (
+            short(r["Name"])[-28:], r["Calls"], int(r["TotalDurationNs"]) / 1e6, float(r["AverageNs"]) / 1e3,
+            100 * int(r["TotalDurationNs"]) / tot, int(r["MinNs"]) / 1e3, int(r["MaxNs"]) / 1e3))
+    out.append("total kernel time %.2f ms; %.1f us per frame over %d frames" % (tot / 1e6, tot / frames / 1e3, frames))
+    return f, "\n".join(out) + "\n"
+
+
+def pmc_means(d, skip=4):
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            agg[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    res = {}
+    for k, cs in agg.items():
+        res[k] = {c: {"mean": float(np.mean(v[skip:] if len(v) > 2 * skip else v)), "launches": len(v)}
+                  for c, v in cs.items()}
+    return res
+
+
+def main():
+    tag, frames, kt, fd, wd = sys.argv[1], int(sys.argv[2]), sys.argv[3], sys.argv[4], sys.argv[5]
+    volume = int(sys.argv[6]) if len(sys.argv) > 6 else 512
+    prof = os.path.join(ROOT, "profiles")
+    os.makedirs(prof, exist_ok=True)
+    stats_csv, text = kernel_summary(kt, frames)
+    shutil.copy(stats_csv, os.path.join(prof, tag + "_kernel_stats.csv"))
+    with open(os.path.join(prof, tag + "_kernel_summary.txt"), "w") as f:
+        f.write(text)
+    pmc = {}
+    for d in (fd, wd):
+        for k, cs in pmc_means(d).items():
+            pmc.setdefault(k, {}).update(cs)
+    with open(os.path.join(prof, tag + "_pmc_per_kernel.json"), "w") as f:
+        json.dump(pmc, f, indent=1, sort_keys=True)
+    ki = pmc["k_integrate"]
+    fetch_kib, write_kib = ki["FETCH_SIZE"]["mean"], ki["WRITE_SIZE"]["mean"]
+    traffic = {
+        "volume": volume,
+        "kernel": "k_integrate",
+        "source": tag + "_pmc_per_kernel.json",
+        "FETCH_SIZE_KiB_per_launch": fetch_kib,
+        "WRITE_SIZE_KiB_per_launch": write_kib,
+        "correction": "bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950: FETCH_SIZE under-counts 128 B requests by half)",
+        "hbm_bytes_per_launch": (2.0 * fetch_kib + write_kib) * 1024.0,
+        "algorithmic_bytes_per_launch": 8.0 * volume ** 3,
+    }
+    with open(os.path.join(prof, "integrate_traffic.json"), "w") as f:
+        json.dump(traffic, f, indent=1)
+    print(text)
+    print(json.dumps(traffic, indent=1))
+
+
+if __name__ == "__main__":
+    main()
