@@ -161,7 +161,8 @@ int kfh_k_track_reduce(float *d_sums, kfh_track_data *d_track, int track_stride,
                        const float Ttrack[16], const float view[16],
                        float dist_threshold, float normal_threshold, void *stream);
 /* solve + updatePoseKernel on the device: pose <- exp(x) * pose; d_x6 receives the twist (6 doubles),
- * d_converged two ints: {|x| < icp_threshold, 1 if the eigen-decomposition path was needed}. */
+ * d_converged two ints: {|x| < icp_threshold, solve path: 0 plain solution (conditioning below the 1e6 limit),
+ * 1 full eigen-decomposition, 2 only the smallest singular value dropped (found by power iteration)}. */
 int kfh_k_update_pose(float *d_pose16, double *d_x6, int *d_converged, const float *d_sums,
                       float icp_threshold, void *stream);
 /* integrateKernel over z in [z0, z1) of a volume whose storage starts at plane z0 */

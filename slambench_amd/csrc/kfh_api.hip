@@ -58,6 +58,7 @@ struct kfh_context {
     int frame = 0;
     int zs0 = 0, zs1 = 0;      // stored planes (slab + halo)
     bool sharded = false;
+    int compute_units = 256;
     hipStream_t stream = nullptr;
 
     uint16_t *h_depth_pinned = nullptr;
@@ -68,14 +69,17 @@ struct kfh_context {
     float4 *d_in_vertex[3] = {nullptr, nullptr, nullptr};
     float4 *d_in_normal[3] = {nullptr, nullptr, nullptr};
     float4 *d_vertex = nullptr, *d_normal = nullptr;
+    float4 *d_ref_tn = nullptr;            // packed model map {hit distance, normal}: what tracking gathers
     float *d_ray_t = nullptr;
+    int depth_version = 0;                 // bumped whenever the depth pyramid changes
+    int in_maps_version[3] = {-1, -1, -1}; // pyramid version the input vertex / normal maps were built from
     short2 *d_volume = nullptr;
     size_t volume_voxels = 0;
     float *d_partials = nullptr;           // two alternating buffers of per-block partial rows
     size_t partials_stride = 0;            // floats per buffer
     Ctrl *d_ctrl = nullptr;
     kfh_frame_status *d_status = nullptr;
-    unsigned long long *d_stamps = nullptr; // diagnostic ICP time stamps (KFH_ICP_STAMPS=1), [64][8]
+    unsigned long long *d_stamps = nullptr; // diagnostic ICP time stamps (KFH_ICP_STAMPS=1), [launch][block][slot]
 
     // phase timing: a ring of event sets, one per frame (slot = frame % KFH_TIMING_RING)
     int timing = 0;            // 0 off, 1 all four phases, 2 integration only
@@ -117,7 +121,7 @@ void free_all(kfh_context *c) {
     if (c->h_depth_pinned) (void)hipHostFree(c->h_depth_pinned);
     void *bufs[] = {c->d_depth_in, c->d_float_depth, c->d_scaled[0], c->d_scaled[1], c->d_scaled[2],
                     c->d_in_vertex[0], c->d_in_vertex[1], c->d_in_vertex[2], c->d_in_normal[0],
-                    c->d_in_normal[1], c->d_in_normal[2], c->d_vertex, c->d_normal, c->d_ray_t, c->d_volume,
+                    c->d_in_normal[1], c->d_in_normal[2], c->d_vertex, c->d_normal, c->d_ray_t, c->d_volume, c->d_ref_tn,
                     c->d_partials, c->d_ctrl, c->d_status, c->d_stamps};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
@@ -136,6 +140,8 @@ int init_state(kfh_context *c) {
     KFH_HIP(hipMemsetAsync(c->d_vertex, 0, npix * sizeof(float4), c->stream));
     KFH_HIP(hipMemsetAsync(c->d_normal, 0, npix * sizeof(float4), c->stream));
     KFH_HIP(hipMemsetAsync(c->d_ray_t, 0, npix * sizeof(float), c->stream));
+    KFH_HIP(hipMemsetAsync(c->d_ref_tn, 0, npix * sizeof(float4), c->stream));
+    for (int l = 0; l < 3; ++l) c->in_maps_version[l] = -1;
     KFH_HIP(hipMemsetAsync(c->d_status, 0, sizeof(kfh_frame_status) * KFH_STATUS_RING, c->stream));
     Ctrl init;
     std::memset(&init, 0, sizeof(init));
@@ -151,11 +157,12 @@ int init_state(kfh_context *c) {
     return KFH_OK;
 }
 
-FinishArgs finish_args(const kfh_context *c, int seq) {
+FinishArgs finish_args(const kfh_context *c, int seq, int pending_rows) {
     FinishArgs a;
     std::memset(&a, 0, sizeof(a));
     a.ctrl = c->d_ctrl;
     a.partials_in = c->d_partials + (size_t)(seq & 1) * c->partials_stride;
+    a.pending_rows = pending_rows;
     a.seq = seq;
     a.w = c->w;
     a.h = c->h;
@@ -220,14 +227,27 @@ int kfh_create(const kfh_config *cfg, kfh_context **out) {
     if (e == hipSuccess) e = dev_alloc(&c->d_vertex, npix);
     if (e == hipSuccess) e = dev_alloc(&c->d_normal, npix);
     if (e == hipSuccess) e = dev_alloc(&c->d_ray_t, npix);
+    if (e == hipSuccess) e = dev_alloc(&c->d_ref_tn, npix);
     if (e == hipSuccess) e = dev_alloc(&c->d_volume, c->volume_voxels);
-    c->partials_stride = (size_t)track_blocks(c->w, c->h) * 32;
+    {
+        hipDeviceProp_t prop;
+        if (e == hipSuccess) e = hipGetDeviceProperties(&prop, c->device);
+        c->compute_units = e == hipSuccess ? prop.multiProcessorCount : 256;
+        int rows = 1;
+        for (int l = 0; l < 3; ++l) {
+            const int wl = c->w >> l, hl = c->h >> l;
+            const int nb = track_blocks(wl, hl, track_ppt(wl, hl, c->compute_units));
+            if (nb > rows) rows = nb;
+        }
+        c->partials_stride = (size_t)rows * 32;
+    }
     if (e == hipSuccess) e = dev_alloc(&c->d_partials, 2 * c->partials_stride);
     if (e == hipSuccess) e = dev_alloc(&c->d_ctrl, 1);
     if (e == hipSuccess) e = dev_alloc(&c->d_status, KFH_STATUS_RING);
     if (e == hipSuccess && std::getenv("KFH_ICP_STAMPS")) {
-        e = dev_alloc(&c->d_stamps, 64 * 8);
-        if (e == hipSuccess) e = hipMemset(c->d_stamps, 0, 64 * 8 * sizeof(unsigned long long));
+        const size_t n = (size_t)KFH_STAMP_LAUNCHES * KFH_STAMP_BLOCKS * KFH_STAMP_SLOTS;
+        e = dev_alloc(&c->d_stamps, n);
+        if (e == hipSuccess) e = hipMemset(c->d_stamps, 0, n * sizeof(unsigned long long));
     }
     if (e != hipSuccess) {
         free_all(c);
@@ -278,6 +298,7 @@ int kfh_preprocess(kfh_context *c) {
     if (c->timing == 1) KFH_HIP(hipEventRecord(c->ev[c->frame % KFH_TIMING_RING][0], c->stream));
     KFH_HIP(launch_preprocess(c->d_float_depth, c->d_scaled[0], c->w, c->h, c->d_depth_cur, true,
                               c->cfg.input_width, c->cfg.compute_size_ratio, c->cfg.depth_divisor, c->stream));
+    c->depth_version++;
     if (c->timing == 1) KFH_HIP(hipEventRecord(c->ev[c->frame % KFH_TIMING_RING][1], c->stream));
     return KFH_OK;
 }
@@ -287,44 +308,44 @@ int kfh_track(kfh_context *c) {
     int total_iterations = 0;
     for (int l = 0; l < 3; ++l) total_iterations += c->cfg.pyramid[l];
     if (c->frame % c->cfg.tracking_rate != 0 || total_iterations == 0) {
-        KFH_HIP(launch_track_skip(finish_args(c, 0), c->stream));
+        KFH_HIP(launch_track_skip(finish_args(c, 0, 0), c->stream));
     } else {
+        c->depth_version++;
         for (int l = 1; l < 3; ++l)
             KFH_HIP(launch_half_sample(c->d_scaled[l], c->d_scaled[l - 1], c->w >> (l - 1), c->h >> (l - 1),
                                        E_DELTA * 3, c->stream));
-        for (int l = 0; l < 3; ++l) {
-            const float s = (float)(1 << l);
-            KFH_HIP(launch_vertex_normal(c->d_in_vertex[l], c->d_in_normal[l], c->d_scaled[l], c->w >> l,
-                                         c->h >> l, c->k[0] / s, c->k[1] / s, c->k[2] / s, c->k[3] / s, c->stream));
-        }
+        // depth2vertex / vertex2normal are evaluated inside the iteration kernel from the depth pyramid;
+        // the vertex / normal maps themselves are only materialised when a caller asks for them
         IcpIterArgs a;
         std::memset(&a, 0, sizeof(a));
         a.ctrl = c->d_ctrl;
-        a.ref_vertex = c->d_vertex;
-        a.ref_normal = c->d_normal;
+        a.ref_tn = c->d_ref_tn;
         a.rw = c->w;
         a.rh = c->h;
         a.dist_threshold = DIST_THRESHOLD;
         a.normal_threshold = NORMAL_THRESHOLD;
         a.icp_threshold = c->cfg.icp_threshold;
         a.stamps = c->d_stamps;
-        int seq = 0;
+        a.max_blocks = c->compute_units;
+        int seq = 0, rows = 0;
         for (int level = 2; level >= 0; --level) {
             a.level = level;
             a.in_depth = c->d_scaled[level];
-            a.in_normal = c->d_in_normal[level];
             for (int i = 0; i < 4; ++i) a.k[i] = c->k[i] / (float)(1 << level);
             a.iw = c->w >> level;
             a.ih = c->h >> level;
+            a.ppt = track_ppt(a.iw, a.ih, c->compute_units);
             for (int i = 0; i < c->cfg.pyramid[level]; ++i, ++seq) {
                 a.seq = seq;
                 a.last_iter = (i == c->cfg.pyramid[level] - 1) ? 1 : 0;
                 a.partials_in = c->d_partials + (size_t)(seq & 1) * c->partials_stride;
                 a.partials_out = c->d_partials + (size_t)((seq + 1) & 1) * c->partials_stride;
+                a.pending_rows = rows;
                 KFH_HIP(launch_icp_iteration(a, c->stream));
+                rows = track_blocks(a.iw, a.ih, a.ppt);
             }
         }
-        KFH_HIP(launch_icp_finish(finish_args(c, seq), c->stream));
+        KFH_HIP(launch_icp_finish(finish_args(c, seq, rows), c->stream));
     }
     if (c->timing) KFH_HIP(hipEventRecord(c->ev[c->frame % KFH_TIMING_RING][2], c->stream));
     return KFH_OK;
@@ -357,8 +378,8 @@ static float raycast_step(const kfh_config &cfg) {
 int kfh_raycast(kfh_context *c) {
     KFH_REQUIRE(c != nullptr, "context is NULL");
     if (c->frame > 2 && !c->sharded) {
-        KFH_HIP(launch_raycast(c->d_vertex, c->d_normal, c->d_ray_t, c->w, c->h, c->d_volume, c->cfg.vol_res,
-                               c->cfg.vol_dim, 0, c->cfg.vol_res[2], &c->d_ctrl->view, NEAR_PLANE, FAR_PLANE,
+        KFH_HIP(launch_raycast(c->d_vertex, c->d_normal, c->d_ray_t, c->d_ref_tn, c->w, c->h, c->d_volume,
+                               c->cfg.vol_res, c->cfg.vol_dim, 0, c->cfg.vol_res[2], &c->d_ctrl->view, NEAR_PLANE, FAR_PLANE,
                                raycast_step(c->cfg), 0.75f * c->cfg.mu, c->stream));
     }
     if (c->timing == 1) {
@@ -371,8 +392,8 @@ int kfh_raycast(kfh_context *c) {
 int kfh_raycast_slab(kfh_context *c) {
     KFH_REQUIRE(c != nullptr, "context is NULL");
     if (c->frame > 2) {
-        KFH_HIP(launch_raycast(c->d_vertex, c->d_normal, c->d_ray_t, c->w, c->h, c->d_volume, c->cfg.vol_res,
-                               c->cfg.vol_dim, c->cfg.slab_z0, c->cfg.slab_z1, &c->d_ctrl->view, NEAR_PLANE,
+        KFH_HIP(launch_raycast(c->d_vertex, c->d_normal, c->d_ray_t, nullptr, c->w, c->h, c->d_volume,
+                               c->cfg.vol_res, c->cfg.vol_dim, c->cfg.slab_z0, c->cfg.slab_z1, &c->d_ctrl->view, NEAR_PLANE,
                                FAR_PLANE, raycast_step(c->cfg), 0.75f * c->cfg.mu, c->stream));
     }
     return KFH_OK;
@@ -382,7 +403,7 @@ int kfh_composite_slabs(kfh_context *c, const float *d_t, const void *d_vertex, 
     KFH_REQUIRE(c != nullptr && d_t && d_vertex && d_normal, "NULL argument");
     KFH_REQUIRE(n_parts >= 1 && n_parts <= 64, "n_parts=%d out of range", n_parts);
     if (c->frame > 2) {
-        KFH_HIP(launch_composite(c->d_vertex, c->d_normal, c->d_ray_t, d_t, static_cast<const float4 *>(d_vertex),
+        KFH_HIP(launch_composite(c->d_vertex, c->d_normal, c->d_ray_t, c->d_ref_tn, d_t, static_cast<const float4 *>(d_vertex),
                                  static_cast<const float4 *>(d_normal), n_parts, c->w * c->h, c->stream));
     }
     return KFH_OK;
@@ -454,8 +475,19 @@ int kfh_device_ptr(kfh_context *c, int buffer, int level, void **d_ptr, size_t *
     switch (buffer) {
         case KFH_BUF_FLOAT_DEPTH: *d_ptr = c->d_float_depth; *bytes = npix * sizeof(float); break;
         case KFH_BUF_SCALED_DEPTH: *d_ptr = c->d_scaled[level]; *bytes = nl * sizeof(float); break;
-        case KFH_BUF_INPUT_VERTEX: *d_ptr = c->d_in_vertex[level]; *bytes = nl * sizeof(float4); break;
-        case KFH_BUF_INPUT_NORMAL: *d_ptr = c->d_in_normal[level]; *bytes = nl * sizeof(float4); break;
+        case KFH_BUF_INPUT_VERTEX:
+        case KFH_BUF_INPUT_NORMAL:
+            // not needed by the pipeline itself: built from the depth pyramid of the last tracked frame on request
+            if (c->in_maps_version[level] != c->depth_version) {
+                const float s = (float)(1 << level);
+                KFH_HIP(launch_vertex_normal(c->d_in_vertex[level], c->d_in_normal[level], c->d_scaled[level],
+                                             c->w >> level, c->h >> level, c->k[0] / s, c->k[1] / s, c->k[2] / s,
+                                             c->k[3] / s, c->stream));
+                c->in_maps_version[level] = c->depth_version;
+            }
+            *d_ptr = buffer == KFH_BUF_INPUT_VERTEX ? (void *)c->d_in_vertex[level] : (void *)c->d_in_normal[level];
+            *bytes = nl * sizeof(float4);
+            break;
         case KFH_BUF_MODEL_VERTEX: *d_ptr = c->d_vertex; *bytes = npix * sizeof(float4); break;
         case KFH_BUF_MODEL_NORMAL: *d_ptr = c->d_normal; *bytes = npix * sizeof(float4); break;
         case KFH_BUF_VOLUME: *d_ptr = c->d_volume; *bytes = c->volume_voxels * sizeof(short2); break;
@@ -518,13 +550,16 @@ int kfh_phase_ms(kfh_context *c, float ms[4]) {
     return kfh_phase_ms_frame(c, c->frame - 1, ms);
 }
 
-// Diagnostic (not part of include/kfusion_hip.h): copy the ICP time stamps of the last frame, 64 x 8 ticks
-// of the 100 MHz real-time counter.  Only filled when the context was created with KFH_ICP_STAMPS set.
+// Diagnostic (not part of include/kfusion_hip.h): copy the ICP time stamps of the last frame,
+// [64 launches][320 blocks][8 slots] ticks of the 100 MHz real-time counter.  Only filled when the context
+// was created with KFH_ICP_STAMPS set.
 int kfh_debug_icp_stamps(kfh_context *c, unsigned long long *h_out) {
     KFH_REQUIRE(c != nullptr && h_out != nullptr, "NULL argument");
     if (!c->d_stamps) return fail(KFH_ERR_STATE, "context was created without KFH_ICP_STAMPS");
     KFH_HIP(hipStreamSynchronize(c->stream));
-    KFH_HIP(hipMemcpy(h_out, c->d_stamps, 64 * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    KFH_HIP(hipMemcpy(h_out, c->d_stamps,
+                      (size_t)KFH_STAMP_LAUNCHES * KFH_STAMP_BLOCKS * KFH_STAMP_SLOTS * sizeof(unsigned long long),
+                      hipMemcpyDeviceToHost));
     return KFH_OK;
 }
 
@@ -572,7 +607,7 @@ int kfh_k_track_reduce(float *d_sums, kfh_track_data *d_track, int track_stride,
     KFH_REQUIRE(k[0] != 0.f && k[1] != 0.f, "focal lengths must be non-zero");
     KFH_REQUIRE(!d_track || track_stride >= iw, "track_stride must be >= iw");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const int nb = track_blocks(iw, ih);
+    const int nb = track_blocks(iw, ih, track_ppt(iw, ih, 256));
     char *scratch = nullptr;   // [control block | partial rows]
     const size_t ctrl_bytes = (sizeof(Ctrl) + 255) & ~(size_t)255;
     KFH_HIP(hipMalloc(reinterpret_cast<void **>(&scratch), ctrl_bytes + (size_t)nb * 32 * sizeof(float)));
@@ -630,7 +665,7 @@ int kfh_k_raycast(void *d_vertex4, void *d_normal4, int w, int h, const void *d_
     KFH_HIP(hipMalloc(reinterpret_cast<void **>(&d_view), sizeof(Mat4)));
     hipError_t e = hipMemcpyAsync(d_view, view, sizeof(Mat4), hipMemcpyHostToDevice, s);
     if (e == hipSuccess)
-        e = launch_raycast(static_cast<float4 *>(d_vertex4), static_cast<float4 *>(d_normal4), nullptr, w, h,
+        e = launch_raycast(static_cast<float4 *>(d_vertex4), static_cast<float4 *>(d_normal4), nullptr, nullptr, w, h,
                            static_cast<const short2 *>(d_volume), res, dim, 0, res[2], d_view, near_plane,
                            far_plane, step, largestep, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);

@@ -29,6 +29,7 @@ struct Ctrl {
     Mat4 project_ref;   // K * inverse(raycast_pose)
     Mat4 inv_pose;      // inverse(pose), input of integrate
     Mat4 view;          // pose * inverse(K), input of raycast
+    Mat4 raycast_view;  // the `view` the model maps were rendered with (rays are rebuilt from it in tracking)
     float sums[32];     // last ICP reduction
     int tracked;        // result of the pose check of this frame
     int integrate_gate; // this frame fuses its depth map: (tracked and rate hit) or frame <= 3
@@ -37,36 +38,58 @@ struct Ctrl {
     IcpState icp[2];    // alternating records of the ICP loop
 };
 
-constexpr int KFH_TRACK_THREADS = 256;
-constexpr int KFH_TRACK_PIX_PER_THREAD = 4;
+// Tracking block: wavefront 0 finalises the previous iteration (row sum, 6x6 solve, pose update) while
+// wavefronts 1..4 prepare and then evaluate the pixels of a 64 x (4 * PPT) tile, PPT rows per thread.
+constexpr int KFH_TRACK_PIXEL_WAVES = 4;
+constexpr int KFH_TRACK_THREADS = 64 * (1 + KFH_TRACK_PIXEL_WAVES);
+constexpr int KFH_TRACK_TILE_W = 64;
+constexpr int KFH_SUM_THREADS = 256;      // block size of the stand-alone row sum / finish kernels
 constexpr int KFH_STATUS_RING = 4096;
+// diagnostic time stamps: [launch][block][slot]
+constexpr int KFH_STAMP_LAUNCHES = 64, KFH_STAMP_BLOCKS = 320, KFH_STAMP_SLOTS = 12;
 
-inline int track_blocks(int w, int h) {
-    const int per_block = KFH_TRACK_THREADS * KFH_TRACK_PIX_PER_THREAD;
-    return (w * h + per_block - 1) / per_block;
+inline int track_blocks(int w, int h, int ppt) {
+    const int tile_h = KFH_TRACK_PIXEL_WAVES * ppt;
+    return ((w + KFH_TRACK_TILE_W - 1) / KFH_TRACK_TILE_W) * ((h + tile_h - 1) / tile_h);
+}
+// Rows per thread for an image: the fewest (of the instantiated 1, 2, 3, 5, 8) whose grid still fits on
+// `max_blocks` compute units at one block each, so that no unit gets a second tile.
+inline int track_ppt(int w, int h, int max_blocks) {
+    const int choices[] = {1, 2, 3, 5, 8};
+    for (int c : choices)
+        if (track_blocks(w, h, c) <= max_blocks) return c;
+    return 8;
 }
 
 struct IcpIterArgs {
     Ctrl *ctrl;
     const float *partials_in;   // rows of the previous iteration launch
     float *partials_out;        // rows of this one
+    int pending_rows;           // rows the previous launch wrote if it evaluated anything (its grid size; 0 for seq 0)
     int seq;                    // position of this launch in the frame's iteration sequence
     int level, last_iter;       // pyramid level; last iteration configured for the level
     const float *in_depth;      // pyramid level of the filtered depth (the input vertex is recomputed from it)
-    const float4 *in_normal;
+    const float4 *in_normal;    // input normal map; null: normals are recomputed from in_depth as well
     float k[4];                 // intrinsics of this level
+    float ik[4];                // set by the launcher: 1/fx, -cx/fx, 1/fy, -cy/fy
     int iw, ih;
-    const float4 *ref_vertex, *ref_normal;
+    const float4 *ref_vertex, *ref_normal;   // model maps, or
+    const float4 *ref_tn;       // (ref_vertex == null) packed model map {hit distance, normal}; the model vertex
+                                // is rebuilt as origin + direction * t from ctrl->raycast_view
     int rw, rh;
     float dist_threshold, normal_threshold, icp_threshold;
+    float dist2_max;            // set by the launcher: largest d2 with sqrtf(d2) <= dist_threshold
+    int ppt;                    // rows per thread (tile height / 4); 0 = chosen by the launcher
+    int max_blocks;             // compute units of the device (for that choice)
     kfh_track_data *track_out;  // per-pixel TrackData for parity tests, may be null
     int track_stride;
-    unsigned long long *stamps; // diagnostic time stamps [seq][8] of block 0, may be null
+    unsigned long long *stamps; // diagnostic time stamps [launch][block][slot], may be null
 };
 
 struct FinishArgs {
     Ctrl *ctrl;
     const float *partials_in;
+    int pending_rows;         // grid size of the last iteration launch
     int seq;                  // number of iteration launches of this frame
     int w, h;                 // compute size (pose check normalisation)
     float icp_threshold;
@@ -101,10 +124,10 @@ hipError_t launch_pose_derive(Ctrl *ctrl, const float k[4], int set_raycast_pose
 hipError_t launch_integrate(short2 *vol, const int res[3], const float dim[3], int z0, int z1,
                             const float *depth, int w, int h, const Mat4 *inv_track, Mat4 K, float mu,
                             float maxweight, const int *gate, hipStream_t s);
-hipError_t launch_raycast(float4 *vertex, float4 *normal, float *ray_t, int w, int h, const short2 *vol,
+hipError_t launch_raycast(float4 *vertex, float4 *normal, float *ray_t, float4 *ref_tn, int w, int h, const short2 *vol,
                           const int res[3], const float dim[3], int z0, int z1, const Mat4 *view,
                           float near_plane, float far_plane, float step, float largestep, hipStream_t s);
-hipError_t launch_composite(float4 *vertex, float4 *normal, float *ray_t, const float *t_parts,
+hipError_t launch_composite(float4 *vertex, float4 *normal, float *ray_t, float4 *ref_tn, const float *t_parts,
                             const float4 *v_parts, const float4 *n_parts, int n_parts_count, int npix,
                             hipStream_t s);
 hipError_t launch_fill_volume(short2 *vol, size_t nvox, hipStream_t s);

@@ -133,6 +133,24 @@ __device__ inline f3 back_project(float d, int x, int y, const Mat4 &invK) {
     return d > 0 ? d * rotate(invK, mk3((float)x, (float)y, 1.f)) : mk3(0, 0, 0);
 }
 
+// vertex2normalKernel for the pixel whose four clamped neighbours have the depths dl / dr / du / dd at the
+// coordinates (xl, y), (xr, y), (x, yu), (x, yd).  Returns false (normal invalid) if a neighbour has no depth.
+__device__ inline bool normal_from_depths(f3 &n, float dl, float dr, float du, float dd, int x, int y, int xl,
+                                          int xr, int yu, int yd, const Mat4 &invK) {
+    const f3 left = back_project(dl, xl, y, invK);
+    const f3 right = back_project(dr, xr, y, invK);
+    const f3 up = back_project(du, x, yu, invK);
+    const f3 down = back_project(dd, x, yd, invK);
+    if (left.z == 0 || right.z == 0 || up.z == 0 || down.z == 0) {
+        n = mk3(KFH_INVALID, 0.f, 0.f);
+        return false;
+    }
+    const f3 dxv = right - left;
+    const f3 dyv = down - up;
+    n = normalize3(cross3(dyv, dxv));
+    return true;
+}
+
 __global__ __launch_bounds__(256) void k_vertex_normal(float4 *__restrict__ vertex, float4 *__restrict__ normal,
                                                        const float *__restrict__ depth, int w, int h,
                                                        Mat4 invK) {
@@ -142,18 +160,10 @@ __global__ __launch_bounds__(256) void k_vertex_normal(float4 *__restrict__ vert
     const int xl = max(x - 1, 0), xr = min(x + 1, w - 1);
     const int yu = max(y - 1, 0), yd = min(y + 1, h - 1);
     const f3 v = back_project(depth[x + y * w], x, y, invK);
-    const f3 left = back_project(depth[xl + y * w], xl, y, invK);
-    const f3 right = back_project(depth[xr + y * w], xr, y, invK);
-    const f3 up = back_project(depth[x + yu * w], x, yu, invK);
-    const f3 down = back_project(depth[x + yd * w], x, yd, invK);
     vertex[x + y * w] = make_float4(v.x, v.y, v.z, 0.f);
-    if (left.z == 0 || right.z == 0 || up.z == 0 || down.z == 0) {
-        normal[x + y * w] = make_float4(KFH_INVALID, 0.f, 0.f, 0.f);
-        return;
-    }
-    const f3 dxv = right - left;
-    const f3 dyv = down - up;
-    const f3 n = normalize3(cross3(dyv, dxv));
+    f3 n;
+    normal_from_depths(n, depth[xl + y * w], depth[xr + y * w], depth[x + yu * w], depth[x + yd * w], x, y, xl, xr,
+                       yu, yd, invK);
     normal[x + y * w] = make_float4(n.x, n.y, n.z, 0.f);
 }
 
@@ -192,57 +202,74 @@ __device__ inline float wave_sum_to_lane63(float v) {
 }
 
 // Fixed-order sum of per-block partial rows (32 floats each) by one block of NT threads.  Eight threads
-// cover one row with float4 loads, so NT/8 rows are fetched per pass and all passes are in flight together;
-// the NT/8 row slots are then folded through LDS in two fixed-order stages.  lds must hold NT*4 floats;
-// the 32 sums are left in lds[0..31].  The result does not depend on scheduling.
+// cover one row with float4 loads, so NT/8 rows are fetched per pass and all passes are in flight together
+// (load_partial_rows: a separate step, so a caller can request the rows long before it needs the sums).
+// stage_partial_rows folds a thread's passes into its row slot in LDS; after a block barrier wavefront 0
+// folds the NT/8 slots (fold_row_slots_wave0).  The result does not depend on scheduling.
 template <int NT>
-__device__ inline void sum_partials_block(float *lds, const float *__restrict__ partials, int nrows) {
-    constexpr int SLOTS = NT / 8;                 // rows fetched per pass
-    constexpr int MAXPASS = 10;                   // passes kept in flight
+struct PartialRows {
+    static constexpr int SLOTS = NT / 8;          // rows fetched per pass
+    static constexpr int MAXPASS = 8;             // passes kept in flight
+    float4 t[MAXPASS];
+};
+
+template <int NT>
+__device__ inline void load_partial_rows(PartialRows<NT> &pr, const float *__restrict__ partials, int nrows,
+                                         int r0 = 0) {
     const int slot = threadIdx.x >> 3, c4 = threadIdx.x & 7;
     const float4 *rows4 = reinterpret_cast<const float4 *>(partials);
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int r0 = 0; r0 < nrows; r0 += SLOTS * MAXPASS) {
-        float4 t[MAXPASS];
 #pragma unroll
-        for (int u = 0; u < MAXPASS; ++u) {
-            const int r = r0 + u * SLOTS + slot;
-            t[u] = r < nrows ? rows4[r * 8 + c4] : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-#pragma unroll
-        for (int u = 0; u < MAXPASS; ++u) {
-            acc.x += t[u].x; acc.y += t[u].y; acc.z += t[u].z; acc.w += t[u].w;
-        }
+    for (int u = 0; u < PartialRows<NT>::MAXPASS; ++u) {
+        const int r = r0 + u * PartialRows<NT>::SLOTS + slot;
+        pr.t[u] = r < nrows ? rows4[r * 8 + c4] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    reinterpret_cast<float4 *>(lds)[slot * 8 + c4] = acc;          // lds[slot][32]
-    __syncthreads();
-    // stage 1: 8 groups x 32 columns, each folds SLOTS/8 consecutive slots
-    float g = 0.f;
-    if (threadIdx.x < 256) {
-        const int col = threadIdx.x & 31, grp = threadIdx.x >> 5;
-#pragma unroll
-        for (int k = 0; k < SLOTS / 8; ++k) g += lds[(grp * (SLOTS / 8) + k) * 32 + col];
-    }
-    __syncthreads();
-    if (threadIdx.x < 256) lds[threadIdx.x] = g;                   // lds[grp][32]
-    __syncthreads();
-    if (threadIdx.x < 32) {
-        float t = lds[threadIdx.x];
-#pragma unroll
-        for (int c = 1; c < 8; ++c) t += lds[c * 32 + threadIdx.x];
-        lds[threadIdx.x] = t;
-    }
-    __syncthreads();
 }
 
-__global__ __launch_bounds__(KFH_TRACK_THREADS) void k_sum_partials(float *sums, const float *partials, int nrows) {
-    __shared__ float lds[KFH_TRACK_THREADS * 4];
-    sum_partials_block<KFH_TRACK_THREADS>(lds, partials, nrows);
-    if (threadIdx.x < 32) sums[threadIdx.x] = lds[threadIdx.x];
+// lds: NT * 4 floats, laid out [slot][32]
+template <int NT>
+__device__ inline void stage_partial_rows(float *lds, PartialRows<NT> &pr, const float *__restrict__ partials,
+                                          int nrows) {
+    constexpr int SLOTS = PartialRows<NT>::SLOTS, MAXPASS = PartialRows<NT>::MAXPASS;
+    const int slot = threadIdx.x >> 3, c4 = threadIdx.x & 7;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int r0 = 0; r0 < nrows; r0 += SLOTS * MAXPASS) {
+        if (r0 > 0) load_partial_rows<NT>(pr, partials, nrows, r0);
+#pragma unroll
+        for (int u = 0; u < MAXPASS; ++u) {
+            acc.x += pr.t[u].x; acc.y += pr.t[u].y; acc.z += pr.t[u].z; acc.w += pr.t[u].w;
+        }
+    }
+    reinterpret_cast<float4 *>(lds)[slot * 8 + c4] = acc;
+}
+
+// Called by the 64 lanes of wavefront 0 after the block barrier that follows stage_partial_rows.
+// Lane l returns sum number (l & 31): each half of the wavefront folds half of the slots in slot order and
+// the two halves are added (a + b == b + a, so both halves hold the same bits).
+template <int NT>
+__device__ inline float fold_row_slots_wave0(const float *lds) {
+    constexpr int HALF = PartialRows<NT>::SLOTS / 2;
+    static_assert(PartialRows<NT>::SLOTS % 2 == 0, "slot count must be even");
+    const int lane = threadIdx.x & 63, col = lane & 31, half = lane >> 5;
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < HALF; ++k) s += lds[(half * HALF + k) * 32 + col];
+    return s + __shfl_xor(s, 32, 64);
+}
+
+__global__ __launch_bounds__(KFH_SUM_THREADS) void k_sum_partials(float *sums, const float *partials, int nrows) {
+    __shared__ float lds[KFH_SUM_THREADS * 4];
+    PartialRows<KFH_SUM_THREADS> pr;
+    load_partial_rows<KFH_SUM_THREADS>(pr, partials, nrows);
+    stage_partial_rows<KFH_SUM_THREADS>(lds, pr, partials, nrows);
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const float s = fold_row_slots_wave0<KFH_SUM_THREADS>(lds);
+        if (threadIdx.x < 32) sums[threadIdx.x] = s;
+    }
 }
 
 hipError_t launch_sum_partials(float *sums, const float *partials, int nrows, hipStream_t s) {
-    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(KFH_TRACK_THREADS), 0, s, sums, partials, nrows);
+    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(KFH_SUM_THREADS), 0, s, sums, partials, nrows);
     return hipGetLastError();
 }
 
@@ -335,6 +362,104 @@ __device__ void jacobi_solve6_wave(double a, const double b[6], double x[6]) {
     for (int m = 0; m < 6; ++m) x[m] = __shfl(xi, m * 8, 64);
 }
 
+// Lanes are laid out lane = 8*row + column.  Sum of v over the 8 lanes of a matrix row, returned in all of
+// them (the same addition tree in every lane, so the lanes agree bit for bit).
+template <int CTRL, int BANK_MASK>
+__device__ inline double dpp_take_f64(double old, double v) {
+    const int lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(v), CTRL, 0xF, BANK_MASK, false);
+    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(v), CTRL, 0xF, BANK_MASK, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ inline double row_sum8_f64(double v) {
+    v = v + dpp_take_f64<0xB1, 0xF>(0.0, v);                  // lane ^ 1
+    v = v + dpp_take_f64<0x4E, 0xF>(0.0, v);                  // lane ^ 2
+    double o = dpp_take_f64<0x104, 0x5>(0.0, v);              // lane ^ 4: banks 0, 2 read lane + 4
+    o = dpp_take_f64<0x114, 0xA>(o, v);                       //           banks 1, 3 read lane - 4
+    return v + o;
+}
+
+// y = M u for the symmetric 6x6 matrix held one element per lane; u and y are wave-uniform 6-vectors.
+__device__ inline void matvec6_wave(double m_elem, const double u[6], double y[6]) {
+    const int j = threadIdx.x & 7;
+    double uj = 0.0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) uj = (j == k) ? u[k] : uj;
+    const double yi = row_sum8_f64(m_elem * uj);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) y[k] = readlane_f64(yi, k * 8);
+}
+
+// Power iteration: dominant eigenpair of the symmetric positive definite 6x6 matrix held one element per
+// lane.  Runs in rounds of 8 products until the residual |M u - theta u| / |theta u| drops below 1e-12;
+// gives up (returns false) after 12 rounds, which happens when the two largest eigenvalues nearly coincide.
+__device__ inline bool dominant_eigenpair_wave(double m_elem, double &theta, double u[6]) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) u[k] = 1.0 + 0.0625 * k;      // generic start
+#pragma unroll 1
+    for (int round = 0; round < 12; ++round) {
+        double y[6];
+#pragma unroll 1
+        for (int it = 0; it < 4; ++it) {
+            matvec6_wave(m_elem, u, y);
+            matvec6_wave(m_elem, y, u);
+        }
+        double big = 0.0;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) big = fmax(big, fabs(u[k]));
+        if (!(big > 0.0) || !(big < 1e300)) return false;
+        const double scale = 1.0 / big;
+        double uu = 0.0;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) { u[k] *= scale; uu += u[k] * u[k]; }
+        matvec6_wave(m_elem, u, y);
+        double uy = 0.0;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) uy += u[k] * y[k];
+        theta = uy / uu;
+        double rr = 0.0;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) { const double r = y[k] - theta * u[k]; rr += r * r; }
+        if (rr <= 1e-24 * theta * theta * uu) {
+            const double inv_norm = 1.0 / sqrt(uu);
+#pragma unroll
+            for (int k = 0; k < 6; ++k) u[k] *= inv_norm;
+            return true;
+        }
+    }
+    return false;
+}
+
+// Middle path for systems just past the conditioning limit, where the truncation rule drops at most the
+// smallest eigenvalue: lambda_max by power iteration on C, lambda_min and its eigenvector v by power
+// iteration on C^-1 (already available from the elimination), then x = C^-1 b - (v.b / lambda_min) v.
+// Returns false when it cannot decide safely (a second eigenvalue near the limit, slow convergence);
+// the caller then runs the full eigen-decomposition.
+__device__ inline bool truncate_smallest_wave(double c_elem, double inv_elem, const double b[6],
+                                              const double x_full[6], double x[6], bool *truncated) {
+    const int lane = threadIdx.x & 63;
+    const int i = lane >> 3, j = lane & 7;
+    const bool in_c = i < 6 && j < 6;
+    double lam_max, mu, ubig[6], v[6];
+    if (!dominant_eigenpair_wave(c_elem, lam_max, ubig)) return false;
+    if (!dominant_eigenpair_wave(in_c ? inv_elem : 0.0, mu, v)) return false;
+    if (!(mu > 0.0) || !(lam_max > 0.0)) return false;
+    // second smallest eigenvalue of C: 1 / lambda_max(C^-1 - mu v v^T) >= 1 / ||C^-1 - mu v v^T||_F
+    double vi = 0.0, vj = 0.0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) { vi = (i == k) ? v[k] : vi; vj = (j == k) ? v[k] : vj; }
+    const double d = in_c ? inv_elem - mu * vi * vj : 0.0;
+    const double fro2 = wave_sum_f64(d * d);
+    if (!(lam_max * lam_max * fro2 < 0.96e12)) return false;      // second eigenvalue not clearly kept
+    const bool keep_min = (1.0 / mu) * 1e6 > lam_max;             // the reference's rule for the smallest
+    double vb = 0.0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) vb += v[k] * b[k];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) x[k] = keep_min ? x_full[k] : x_full[k] - mu * vb * v[k];
+    *truncated = !keep_min;
+    return true;
+}
+
 // Called by all 64 lanes of one wavefront; vals = 27 floats {b[6], upper triangle of C}.  x is returned
 // in every lane.  *used_jacobi (may be null) reports which path produced it.
 __device__ void solve_normal_equations_wave(const float *vals, double x[6], int *used_jacobi) {
@@ -377,16 +502,28 @@ __device__ void solve_normal_equations_wave(const float *vals, double x[6], int 
     const float fro_i2 = readlane63(wave_sum_to_lane63(in_c ? (float)inv * (float)inv : 0.f));
     // (||C||_F ||C^-1||_F)^2 < (1e6)^2, with 1 % slack for the float norms
     const bool certified = spd && ((double)fro_c2 * (double)fro_i2 < 0.98e12);
+    double xf[6];
+#pragma unroll
+    for (int m = 0; m < 6; ++m) xf[m] = readlane_f64(a, m * 8 + 6);
+    int path = 0;                                    // 0 plain solution, 1 eigen-decomposition, 2 smallest dropped
     if (certified) {
 #pragma unroll
-        for (int m = 0; m < 6; ++m) x[m] = __shfl(a, m * 8 + 6, 64);
+        for (int m = 0; m < 6; ++m) x[m] = xf[m];
     } else {
         double b[6];
 #pragma unroll
         for (int m = 0; m < 6; ++m) b[m] = (double)vals[m];
-        jacobi_solve6_wave(c_elem, b, x);
+        bool truncated = false;
+        // C^-1 from the elimination is accurate enough for the middle path while cond(C) < ~1e9
+        if (spd && (double)fro_c2 * (double)fro_i2 < 1e18 &&
+            truncate_smallest_wave(c_elem, inv, b, xf, x, &truncated)) {
+            path = truncated ? 2 : 0;
+        } else {
+            jacobi_solve6_wave(c_elem, b, x);
+            path = 1;
+        }
     }
-    if (used_jacobi) *used_jacobi = certified ? 0 : 1;
+    if (used_jacobi) *used_jacobi = path;
 }
 
 // SE(3) exponential of a twist (translation first, rotation last), double in, float 4x4 out.
@@ -465,6 +602,7 @@ __device__ void derive_matrices(Ctrl *c, const float k[4], bool set_raycast_pose
     c->view = mat_mul(c->pose, inverse_camera_matrix(k[0], k[1], k[2], k[3]));
     if (set_raycast_pose) {
         c->raycast_pose = c->pose;
+        c->raycast_view = c->view;
         c->project_ref = mat_mul(camera_matrix(k[0], k[1], k[2], k[3]), mat_inverse(c->raycast_pose));
     }
     c->old_pose = c->pose;
@@ -525,54 +663,66 @@ __device__ void finish_tracking(const FinishArgs &a, bool ran_tracking, int iter
 // sum J J^T, [28] valid, [29] result==-4, [30] result==-5, [31] result in {-1,-2,-3}.
 // Algorithmic bytes: 64 B per pixel (in vertex+normal, gathered reference vertex+normal) + 128 B per block.
 // =====================================================================================================
+// Division by a shared denominator, bit-identical to IEEE division while no intermediate leaves the
+// normal range: the reciprocal estimate is refined once and each quotient takes two residual corrections.
+__device__ inline float refined_rcp(float d) {
+    const float r = __builtin_amdgcn_rcpf(d);
+    return fmaf(fmaf(-d, r, 1.f), r, r);
+}
+__device__ inline float div_shared(float n, float d, float r1) {
+    const float q0 = n * r1;
+    const float q1 = fmaf(fmaf(-d, q0, n), r1, q0);
+    return fmaf(fmaf(-d, q1, n), r1, q1);
+}
+
 struct IcpShared {
-    float tr[32 * KFH_TRACK_THREADS];   // transpose buffer of the block reduction (64 KiB)
-    float red[KFH_TRACK_THREADS * 4];   // partial-row slots, then the sums in red[0..31]
+    float slots[KFH_TRACK_THREADS * 4];        // row slots of the pending sum, [slot][32]
+    float sums[32];                            // reduction of the last finalised iteration
+    float part[KFH_TRACK_PIXEL_WAVES][32];     // this iteration's sums per pixel wavefront
     Mat4 pose;
     int done_mask, iterations, slow_solves;
 };
 
-// Called by every thread of a KFH_TRACK_THREADS block.  Leaves pose / sums / counters after the pending
-// iteration (if any) in `sh`.
-__device__ inline void icp_finalize_pending(const IcpState *__restrict__ in, const float *__restrict__ partials_in,
-                                            float icp_threshold, IcpShared &sh,
-                                            unsigned long long *stamps = nullptr) {
-    const int pend = in->pending_nblocks;            // uniform
-    const Mat4 pose_in = in->pose;                   // requested now, needed after the partial sums
+// Wavefront 0: fold the staged rows, solve, update the pose; or carry the record over when nothing is pending.
+template <int NT>
+__device__ inline void icp_finalize_wave0(const IcpState *__restrict__ in, Mat4 pose, int pend, float icp_threshold,
+                                          const float *slots, float *sums_lds, Mat4 *pose_lds, int *done_mask_lds,
+                                          int *iterations_lds, int *slow_lds) {
+    const int lane = threadIdx.x & 63;
+    const int in_done_mask = in->done_mask, in_last = in->pending_last, in_level = in->pending_level;
+    const int in_iterations = in->iterations, in_slow = in->slow_solves;
     if (pend > 0) {
-        sum_partials_block<KFH_TRACK_THREADS>(sh.red, partials_in, pend);
-        if (stamps && blockIdx.x == 0 && threadIdx.x == 0) stamps[6] = __builtin_amdgcn_s_memrealtime();
-        if (threadIdx.x < 64) {                      // the solve runs on wavefront 0
-            Mat4 pose = pose_in;
-            double x[6];
-            int slow;
-            const bool converged = update_pose_wave(pose, sh.red, icp_threshold, x, &slow);
-            if (threadIdx.x == 0) {
-                sh.pose = pose;
-                const bool level_finished = converged || in->pending_last != 0;
-                sh.done_mask = in->done_mask | (level_finished ? (1 << in->pending_level) : 0);
-                sh.iterations = in->iterations + 1;
-                sh.slow_solves = in->slow_solves + slow;
-                if (stamps && blockIdx.x == 0) stamps[7] = __builtin_amdgcn_s_memrealtime();
-            }
+        const float sum = fold_row_slots_wave0<NT>(slots);
+        if (lane < 32) sums_lds[lane] = sum;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        double x[6];
+        int slow;
+        const bool converged = update_pose_wave(pose, sums_lds, icp_threshold, x, &slow);
+        if (lane == 0) {
+            const bool level_finished = converged || in_last != 0;
+            *done_mask_lds = in_done_mask | (level_finished ? (1 << in_level) : 0);
+            *iterations_lds = in_iterations + 1;
+            *slow_lds = in_slow + (slow == 1 ? 1 : 0);
         }
     } else {
-        if (threadIdx.x < 32) sh.red[threadIdx.x] = in->sums[threadIdx.x];
-        if (threadIdx.x == 0) {
-            sh.pose = pose_in;
-            sh.done_mask = in->done_mask;
-            sh.iterations = in->iterations;
-            sh.slow_solves = in->slow_solves;
+        if (lane < 32) sums_lds[lane] = in->sums[lane];
+        if (lane == 0) {
+            *done_mask_lds = in_done_mask;
+            *iterations_lds = in_iterations;
+            *slow_lds = in_slow;
         }
     }
-    __syncthreads();
+    if (lane == 0) *pose_lds = pose;
 }
 
+// one wavefront of block 0: lanes 0..31 store the sums, lane 0 the rest
 __device__ inline void icp_store_state(IcpState *out, const IcpShared &sh, int pending_nblocks, int level,
                                        int last_iter) {
-    // one wavefront of block 0: lanes 0..31 store the sums, lane 0 the rest
-    if (threadIdx.x < 32) out->sums[threadIdx.x] = sh.red[threadIdx.x];
-    if (threadIdx.x == 0) {
+    const int lane = threadIdx.x & 63;
+    if (lane < 32) out->sums[lane] = sh.sums[lane];
+    if (lane == 0) {
         out->pose = sh.pose;
         out->pending_nblocks = pending_nblocks;
         out->pending_level = level;
@@ -583,177 +733,425 @@ __device__ inline void icp_store_state(IcpState *out, const IcpShared &sh, int p
     }
 }
 
-// Diagnostic time stamps (100 MHz real-time counter) of block 0, taken only in the STAMPS instantiation.
-#define KFH_STAMP(slot)                                                                       \
-    do {                                                                                      \
-        if (STAMPS && blockIdx.x == 0 && threadIdx.x == 0) {                                  \
-            __builtin_amdgcn_sched_barrier(0);                                                \
-            a.stamps[a.seq * 8 + (slot)] = __builtin_amdgcn_s_memrealtime();                  \
-            __builtin_amdgcn_sched_barrier(0);                                                \
-        }                                                                                     \
+// Diagnostic time stamps (100 MHz real-time counter) of lane 0 of wavefront w, when a stamp buffer is given.
+#define KFH_STAMP(slot, w)                                                                                   \
+    do {                                                                                                     \
+        if (a.stamps != nullptr && threadIdx.x == 64 * (w) && blockIdx.x < KFH_STAMP_BLOCKS &&               \
+            a.seq < KFH_STAMP_LAUNCHES) {                                                                    \
+            __builtin_amdgcn_sched_barrier(0);                                                               \
+            a.stamps[((size_t)a.seq * KFH_STAMP_BLOCKS + blockIdx.x) * KFH_STAMP_SLOTS + (slot)] =           \
+                __builtin_amdgcn_s_memrealtime();                                                            \
+            __builtin_amdgcn_sched_barrier(0);                                                               \
+        }                                                                                                    \
     } while (0)
 
-template <bool STAMPS>
-__global__ __launch_bounds__(KFH_TRACK_THREADS) void k_icp_iteration(IcpIterArgs a) {
-    constexpr int PPT = KFH_TRACK_PIX_PER_THREAD;
-    __shared__ IcpShared sh;
-    KFH_STAMP(0);
-    const int npix = a.iw * a.ih;
-    const int base = blockIdx.x * (KFH_TRACK_THREADS * PPT) + threadIdx.x;
+// v0 <- {v0 lanes 0..31, v1 lanes 0..31}; v1 <- {v0 lanes 32..63, v1 lanes 32..63}
+__device__ inline void swap_halves(float &v0, float &v1) {
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(v0), "+v"(v1));
+}
+// the same between the even and odd 16-lane rows of each half
+__device__ inline void swap_rows(float &v0, float &v1) {
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(v0), "+v"(v1));
+}
+template <int CTRL, int BANK_MASK>
+__device__ inline float dpp_take(float old, float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old),
+                                                                 __builtin_bit_cast(int, v), CTRL, 0xF, BANK_MASK, false));
+}
 
-    // this iteration's input pixels: in flight while the previous iteration is finalised
-    float4 nin4[PPT];
-    float din[PPT];
-    int pcl[PPT];
+// Sum each of 32 per-lane values over the 64 lanes of a wavefront.  Instead of 32 full reductions the
+// values are halved at every step: partners (lane ^ 32, ^ 16, ^ 8, ^ 4, ^ 2) each keep one half of the
+// values and add the partner's copy of that half; after five steps a lane holds one value, and a last
+// add with lane ^ 1 completes it.  Returns the total of value number (lane >> 1).  Fixed order, 31 exchanges.
+__device__ inline float wave_reduce32(float (&v)[32]) {
+    const int lane = threadIdx.x & 63;
+    // lane ^ 32: lower half keeps v[0..15], upper half v[16..31]
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        swap_halves(v[i], v[16 + i]);
+        v[i] = v[i] + v[16 + i];
+    }
+    // lane ^ 16: even rows keep v[0..7], odd rows v[8..15]
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        swap_rows(v[i], v[8 + i]);
+        v[i] = v[i] + v[8 + i];
+    }
+    // lane ^ 8 (rotate the 16-lane row by 8)
+    const bool b3 = lane & 8, b2 = lane & 4, b1 = lane & 2;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float keep = b3 ? v[4 + i] : v[i], give = b3 ? v[i] : v[4 + i];
+        v[i] = keep + dpp_take<0x128, 0xF>(0.f, give);                 // row_ror:8
+    }
+    // lane ^ 4: banks 0 and 2 read from lane + 4, banks 1 and 3 from lane - 4
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const float keep = b2 ? v[2 + i] : v[i], give = b2 ? v[i] : v[2 + i];
+        float got = dpp_take<0x104, 0x5>(0.f, give);                   // row_shl:4 into banks 0, 2
+        got = dpp_take<0x114, 0xA>(got, give);                         // row_shr:4 into banks 1, 3
+        v[i] = keep + got;
+    }
+    // lane ^ 2
+    {
+        const float keep = b1 ? v[1] : v[0], give = b1 ? v[0] : v[1];
+        v[0] = keep + dpp_take<0x4E, 0xF>(0.f, give);                  // quad_perm [2,3,0,1]
+    }
+    // lane ^ 1: both lanes of a pair hold the same value index
+    return v[0] + dpp_take<0xB1, 0xF>(0.f, v[0]);                      // quad_perm [1,0,3,2]
+}
+
+// PACKED: the pipeline's form.  Input normals are recomputed from the depth pyramid (five depths per pixel
+// instead of a 16-byte normal), the model map is the packed {t, normal} image written by the raycast and
+// the model vertex is rebuilt from the ray through the reference pixel.  !PACKED: caller-provided maps.
+//
+// Timeline of a block: all loads that do not depend on the pose (input depths, the previous launch's
+// partial rows) are requested at entry.  Wavefront 0 then finalises the previous iteration; meanwhile the
+// pixel wavefronts project their pixels with the pose of BEFORE that update and gather the model map there
+// (the update moves few projections across a pixel boundary), and compute the input normals.  With the new
+// pose only pixels whose reference index changed are gathered again.
+template <bool PACKED, int PPT>
+__global__ __launch_bounds__(KFH_TRACK_THREADS) void k_icp_iteration(IcpIterArgs a) {
+    __shared__ IcpShared sh;
+    KFH_STAMP(0, 0);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int pw = wave - 1;                          // pixel wavefront index; wavefront 0 has no pixels
+    const IcpState *in = &a.ctrl->icp[a.seq & 1];
+    IcpState *out = &a.ctrl->icp[(a.seq + 1) & 1];
+
+    PartialRows<KFH_TRACK_THREADS> pr;
+    load_partial_rows<KFH_TRACK_THREADS>(pr, a.partials_in, a.pending_rows);
+
+    const int tile_h = KFH_TRACK_PIXEL_WAVES * PPT;
+    const int tiles_x = (a.iw + KFH_TRACK_TILE_W - 1) / KFH_TRACK_TILE_W;
+    const int tile_y = blockIdx.x / tiles_x, tile_x = blockIdx.x - tile_y * tiles_x;
+    const int x_raw = tile_x * KFH_TRACK_TILE_W + lane;
+    const int y0 = tile_y * tile_h + max(pw, 0) * PPT;
+    const int x = min(x_raw, a.iw - 1);               // clamped: every load stays inside the image
+    const int xl = max(x - 1, 0), xr = min(x + 1, a.iw - 1);
+
+    float dcol[PPT + 2], dlft[PPT], drgt[PPT];        // PACKED: rows y0-1 .. y0+PPT of the column, left, right
+    float4 nin4[PPT];                                 // !PACKED
+    int yy[PPT];
     bool live[PPT];
 #pragma unroll
     for (int k = 0; k < PPT; ++k) {
-        const int p = base + k * KFH_TRACK_THREADS;
-        live[k] = p < npix;
-        pcl[k] = live[k] ? p : 0;
-        nin4[k] = a.in_normal[pcl[k]];
-        din[k] = a.in_depth[pcl[k]];
+        live[k] = x_raw < a.iw && y0 + k < a.ih;
+        yy[k] = min(y0 + k, a.ih - 1);
+    }
+    if (pw >= 0) {
+        if (PACKED) {
+#pragma unroll
+            for (int k = 0; k < PPT + 2; ++k) dcol[k] = a.in_depth[x + min(max(y0 - 1 + k, 0), a.ih - 1) * a.iw];
+#pragma unroll
+            for (int k = 0; k < PPT; ++k) {
+                dlft[k] = a.in_depth[xl + yy[k] * a.iw];
+                drgt[k] = a.in_depth[xr + yy[k] * a.iw];
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < PPT; ++k) {
+                dcol[k + 1] = a.in_depth[x + yy[k] * a.iw];
+                nin4[k] = a.in_normal[x + yy[k] * a.iw];
+            }
+        }
     }
 
-    const IcpState *in = &a.ctrl->icp[a.seq & 1];
-    IcpState *out = &a.ctrl->icp[(a.seq + 1) & 1];
-    icp_finalize_pending(in, a.partials_in, a.icp_threshold, sh, STAMPS ? a.stamps + a.seq * 8 : nullptr);
-    KFH_STAMP(1);
+    // everything the block reads from the control block is requested here, ahead of the first barrier
+    const int pend = in->pending_nblocks;             // uniform
+    const int in_done_mask = in->done_mask;
+    const Mat4 pose_old = in->pose;
+    const Mat4 view = a.ctrl->project_ref;
+    Mat4 rview;
+    if (PACKED) rview = a.ctrl->raycast_view;
+    if (pend == 0 && ((in_done_mask >> a.level) & 1)) {
+        // the level finished in an earlier launch: carry the record over
+        if (blockIdx.x == 0 && wave == 0) {
+            if (lane < 32) out->sums[lane] = in->sums[lane];
+            if (lane == 0) {
+                out->pose = pose_old;
+                out->pending_nblocks = 0;
+                out->pending_level = a.level;
+                out->pending_last = 0;
+                out->done_mask = in_done_mask;
+                out->iterations = in->iterations;
+                out->slow_solves = in->slow_solves;
+            }
+        }
+        return;
+    }
+    if (pend > 0) stage_partial_rows<KFH_TRACK_THREADS>(sh.slots, pr, a.partials_in, pend);
+    __syncthreads();
+    KFH_STAMP(1, 0);
 
-    if (sh.done_mask & (1 << a.level)) {             // this level already finished: nothing to evaluate
-        if (blockIdx.x == 0) icp_store_state(out, sh, 0, a.level, 0);
+    const Mat4 invK = {{a.ik[0], 0, a.ik[1], 0, 0, a.ik[2], a.ik[3], 0, 0, 0, 1, 0, 0, 0, 0, 1}};
+    f3 vin[PPT], nin[PPT];
+    float4 rsa[PPT], rsb[PPT];                        // gathered model map (PACKED: rsa = {t, normal})
+    unsigned sidx[PPT];
+    if (wave == 0) {
+        icp_finalize_wave0<KFH_TRACK_THREADS>(in, pose_old, pend, a.icp_threshold, sh.slots, sh.sums, &sh.pose,
+                                              &sh.done_mask, &sh.iterations, &sh.slow_solves);
+    } else {
+        // Branch-free on purpose: the PPT pixels are independent dependency chains (divisions, square
+        // roots) that the scheduler can only interleave inside one basic block.
+        if (PACKED) {
+            f3 vcol[PPT + 2];                         // vertices of the column, rows y0-1 .. y0+PPT (clamped)
+#pragma unroll
+            for (int k = 0; k < PPT + 2; ++k)
+                vcol[k] = back_project(dcol[k], x, min(max(y0 - 1 + k, 0), a.ih - 1), invK);
+#pragma unroll
+            for (int k = 0; k < PPT; ++k) {
+                // vertex2normalKernel: the vertices above and below are the column's own neighbours
+                vin[k] = vcol[k + 1];
+                const f3 left = back_project(dlft[k], xl, yy[k], invK);
+                const f3 right = back_project(drgt[k], xr, yy[k], invK);
+                const f3 up = vcol[k], down = vcol[k + 2];
+                const bool hole = left.z == 0 || right.z == 0 || up.z == 0 || down.z == 0;
+                const f3 n = normalize3(cross3(down - up, right - left));
+                nin[k] = hole ? mk3(KFH_INVALID, 0.f, 0.f) : n;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < PPT; ++k) {
+                vin[k] = back_project(dcol[k + 1], x, yy[k], invK);
+                nin[k] = mk3(nin4[k].x, nin4[k].y, nin4[k].z);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < PPT; ++k) {
+            // where the pixel projected with the previous pose (approximate arithmetic is enough here);
+            // gathering there brings the model map lines into the caches before the new pose is known
+            const f3 pp = xform(view, xform(pose_old, vin[k]));
+            const float r = __builtin_amdgcn_rcpf(pp.z);
+            const float sx = fminf(fmaxf(pp.x * r + 0.5f, 0.f), (float)(a.rw - 1));
+            const float sy = fminf(fmaxf(pp.y * r + 0.5f, 0.f), (float)(a.rh - 1));
+            sidx[k] = (unsigned)sx + (unsigned)sy * (unsigned)a.rw;
+        }
+#pragma unroll
+        for (int k = 0; k < PPT; ++k) {
+            if (PACKED) {
+                rsa[k] = a.ref_tn[sidx[k]];
+            } else {
+                rsa[k] = a.ref_normal[sidx[k]];
+                rsb[k] = a.ref_vertex[sidx[k]];
+            }
+        }
+    }
+    KFH_STAMP(2, 0);
+    KFH_STAMP(7, 1);
+    KFH_STAMP(8, 4);
+    __syncthreads();
+    KFH_STAMP(3, 1);
+
+    if (sh.done_mask & (1 << a.level)) {             // the pending iteration finished this level
+        if (blockIdx.x == 0 && wave == 0) icp_store_state(out, sh, 0, a.level, 0);
         return;
     }
 
-    Mat4 Ttrack;
+    if (wave != 0) {
+        Mat4 Ttrack;
 #pragma unroll
-    for (int i = 0; i < 16; ++i)
-        Ttrack.m[i] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, sh.pose.m[i])));
-    const Mat4 view = a.ctrl->project_ref;
-
-    f3 projectedVertex[PPT];
-    bool img_ok[PPT];
-    unsigned ridx[PPT];
-    const Mat4 invK = inverse_camera_matrix(a.k[0], a.k[1], a.k[2], a.k[3]);
+        for (int i = 0; i < 16; ++i)
+            Ttrack.m[i] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, sh.pose.m[i])));
+        f3 projectedVertex[PPT], projectedPos[PPT];
+        bool img_ok[PPT];
+        float px[PPT], py[PPT], rxf[PPT], ryf[PPT];
+        bool all_fast = true;
 #pragma unroll
-    for (int k = 0; k < PPT; ++k) {
-        // the input vertex is depth2vertexKernel's expression, re-evaluated from the 4-byte depth instead of
-        // reading the 16-byte vertex map
-        const int py_in = pcl[k] / a.iw, px_in = pcl[k] - py_in * a.iw;
-        const f3 vin = back_project(din[k], px_in, py_in, invK);
-        projectedVertex[k] = xform(Ttrack, vin);
-        const f3 projectedPos = xform(view, projectedVertex[k]);
-        const float px = projectedPos.x / projectedPos.z + 0.5f;
-        const float py = projectedPos.y / projectedPos.z + 0.5f;
-        img_ok[k] = !(px < 0 || px > a.rw - 1 || py < 0 || py > a.rh - 1);
-        const bool fetch = img_ok[k] && nin4[k].x != KFH_INVALID;
-        ridx[k] = fetch ? (unsigned)px + (unsigned)py * (unsigned)a.rw : 0u;
-    }
-    float4 rn4[PPT], rv4[PPT];
-#pragma unroll
-    for (int k = 0; k < PPT; ++k) {
-        rn4[k] = a.ref_normal[ridx[k]];
-        rv4[k] = a.ref_vertex[ridx[k]];
-    }
-
-    KFH_STAMP(2);
-    float acc[32];
-#pragma unroll
-    for (int i = 0; i < 32; ++i) acc[i] = 0.0f;
-#pragma unroll
-    for (int k = 0; k < PPT; ++k) {
-        const f3 referenceNormal = mk3(rn4[k].x, rn4[k].y, rn4[k].z);
-        const f3 diff = mk3(rv4[k].x, rv4[k].y, rv4[k].z) - projectedVertex[k];
-        const f3 projectedNormal = rotate(Ttrack, mk3(nin4[k].x, nin4[k].y, nin4[k].z));
-        const bool dist_bad = length3(diff) > a.dist_threshold;
-        const bool normal_bad = dot3(projectedNormal, referenceNormal) < a.normal_threshold;
-        const int result = nin4[k].x == KFH_INVALID ? -1
-                           : !img_ok[k]            ? -2
-                           : rn4[k].x == KFH_INVALID ? -3
-                           : dist_bad              ? -4
-                           : normal_bad            ? -5
-                                                   : 1;
-        const bool valid = result == 1;
-        const f3 c = cross3(projectedVertex[k], referenceNormal);
-        const float error = valid ? dot3(referenceNormal, diff) : 0.f;
-        float J[6];
-        J[0] = valid ? referenceNormal.x : 0.f; J[1] = valid ? referenceNormal.y : 0.f;
-        J[2] = valid ? referenceNormal.z : 0.f;
-        J[3] = valid ? c.x : 0.f; J[4] = valid ? c.y : 0.f; J[5] = valid ? c.z : 0.f;
-        if (a.track_out && live[k]) {
-            const int p = base + k * KFH_TRACK_THREADS;
-            const int y = p / a.iw, x = p - y * a.iw;
-            kfh_track_data td;
-            td.result = result;
-            td.error = error;
-            for (int i = 0; i < 6; ++i) td.J[i] = J[i];
-            a.track_out[x + y * a.track_stride] = td;
+        for (int k = 0; k < PPT; ++k) {
+            projectedVertex[k] = xform(Ttrack, vin[k]);
+            projectedPos[k] = xform(view, projectedVertex[k]);
+            const f3 p = projectedPos[k];
+            // x / z and y / z share one reciprocal; bit-identical to IEEE division while no intermediate leaves
+            // the normal range, which the range test guarantees
+            const float az = fabsf(p.z), ax = fabsf(p.x), ay = fabsf(p.y);
+            const bool fast = az > 1e-12f && az < 1e12f && ax < 1e12f && ay < 1e12f && ax > 1e-12f * az &&
+                              ay > 1e-12f * az;
+            all_fast = all_fast && fast;
+            const float r1 = refined_rcp(p.z);
+            px[k] = div_shared(p.x, p.z, r1) + 0.5f;
+            py[k] = div_shared(p.y, p.z, r1) + 0.5f;
         }
-        const bool count = live[k];
-        acc[0] += (count ? error : 0.f) * error;
+        if (!all_fast) {                              // rare: operands near the ends of the float range
 #pragma unroll
-        for (int i = 0; i < 6; ++i) acc[1 + i] += (count ? error : 0.f) * J[i];
-        int q = 7;
+            for (int k = 0; k < PPT; ++k) {
+                px[k] = projectedPos[k].x / projectedPos[k].z + 0.5f;
+                py[k] = projectedPos[k].y / projectedPos[k].z + 0.5f;
+            }
+        }
+        unsigned ridx[PPT];
 #pragma unroll
-        for (int i = 0; i < 6; ++i)
+        for (int k = 0; k < PPT; ++k) {
+            img_ok[k] = !(px[k] < 0 || px[k] > a.rw - 1 || py[k] < 0 || py[k] > a.rh - 1);
+            const unsigned rx = img_ok[k] ? (unsigned)px[k] : 0u, ry = img_ok[k] ? (unsigned)py[k] : 0u;
+            rxf[k] = (float)rx;
+            ryf[k] = (float)ry;
+            ridx[k] = rx + ry * (unsigned)a.rw;
+        }
+        // the speculative gathers have done their work (their lines are cached); retire them
 #pragma unroll
-            for (int j = i; j < 6; ++j) acc[q++] += (count ? J[i] : 0.f) * J[j];
-        acc[28] += (count && valid) ? 1.f : 0.f;
-        acc[29] += (count && result == -4) ? 1.f : 0.f;
-        acc[30] += (count && result == -5) ? 1.f : 0.f;
-        acc[31] += (count && result < 1 && result > -4) ? 1.f : 0.f;
+        for (int k = 0; k < PPT; ++k) {
+            asm volatile("" ::"v"(rsa[k].x), "v"(rsa[k].y), "v"(rsa[k].z), "v"(rsa[k].w));
+            if (!PACKED) asm volatile("" ::"v"(rsb[k].x), "v"(rsb[k].y), "v"(rsb[k].z), "v"(rsb[k].w));
+        }
+#pragma unroll
+        for (int k = 0; k < PPT; ++k) {
+            if (PACKED) {
+                rsa[k] = a.ref_tn[ridx[k]];
+            } else {
+                rsa[k] = a.ref_normal[ridx[k]];
+                rsb[k] = a.ref_vertex[ridx[k]];
+            }
+        }
+        KFH_STAMP(4, 1);
+        float acc[32];
+#pragma unroll
+        for (int i = 0; i < 32; ++i) acc[i] = 0.0f;
+#pragma unroll
+        for (int k = 0; k < PPT; ++k) {
+            f3 referenceNormal, refVertex;
+            if (PACKED) {
+                // the raycast stored vertex = origin + direction * t with direction = rotate(view, (x, y, 1)):
+                // the same expression on the same matrix gives the same bits
+                const f3 rorigin = mk3(rview.m[3], rview.m[7], rview.m[11]);
+                const f3 rdir = rotate(rview, mk3(rxf[k], ryf[k], 1.f));
+                const float t = rsa[k].x;
+                const f3 p = rorigin + rdir * t;
+                refVertex = t > 0.0f ? p : mk3(0.f, 0.f, 0.f);
+                referenceNormal = mk3(rsa[k].y, rsa[k].z, rsa[k].w);
+            } else {
+                refVertex = mk3(rsb[k].x, rsb[k].y, rsb[k].z);
+                referenceNormal = mk3(rsa[k].x, rsa[k].y, rsa[k].z);
+            }
+            const f3 diff = refVertex - projectedVertex[k];
+            const f3 projectedNormal = rotate(Ttrack, nin[k]);
+            const bool dist_bad = dot3(diff, diff) > a.dist2_max;      // length(diff) > dist_threshold
+            const bool normal_bad = dot3(projectedNormal, referenceNormal) < a.normal_threshold;
+            const int result = nin[k].x == KFH_INVALID ? -1
+                               : !img_ok[k]            ? -2
+                               : referenceNormal.x == KFH_INVALID ? -3
+                               : dist_bad              ? -4
+                               : normal_bad            ? -5
+                                                       : 1;
+            const bool valid = result == 1;
+            const f3 c = cross3(projectedVertex[k], referenceNormal);
+            const float error = valid ? dot3(referenceNormal, diff) : 0.f;
+            float J[6];
+            J[0] = valid ? referenceNormal.x : 0.f; J[1] = valid ? referenceNormal.y : 0.f;
+            J[2] = valid ? referenceNormal.z : 0.f;
+            J[3] = valid ? c.x : 0.f; J[4] = valid ? c.y : 0.f; J[5] = valid ? c.z : 0.f;
+            if (!PACKED && a.track_out && live[k]) {
+                kfh_track_data td;
+                td.result = result;
+                td.error = error;
+                for (int i = 0; i < 6; ++i) td.J[i] = J[i];
+                a.track_out[x + yy[k] * a.track_stride] = td;
+            }
+            // rows and columns past the image edge repeat the edge pixel: they add zeros
+            const float e = live[k] ? error : 0.f;
+            float Jl[6];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) Jl[i] = live[k] ? J[i] : 0.f;
+            acc[0] += e * e;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) acc[1 + i] += e * Jl[i];
+            int q = 7;
+#pragma unroll
+            for (int i = 0; i < 6; ++i)
+#pragma unroll
+                for (int j = i; j < 6; ++j) acc[q++] += Jl[i] * Jl[j];
+            acc[28] += (live[k] && valid) ? 1.f : 0.f;
+            acc[29] += (live[k] && result == -4) ? 1.f : 0.f;
+            acc[30] += (live[k] && result == -5) ? 1.f : 0.f;
+            acc[31] += (live[k] && result < 1 && result > -4) ? 1.f : 0.f;
+        }
+        KFH_STAMP(5, 1);
+        KFH_STAMP(9, 4);
+        const float total = wave_reduce32(acc);
+        if ((lane & 1) == 0) sh.part[pw][lane >> 1] = total;
+        KFH_STAMP(10, 4);
     }
-
-    KFH_STAMP(3);
-    // Block reduction of the 32 sums through LDS: thread t stores value v at tr[v][t]; then THREADS/32 threads
-    // per value each fold 32 consecutive entries (start rotated by the part index, so the threads of a value
-    // hit different banks) and a DPP row reduction folds the parts.  Fixed order, no atomics.
-    float *tr = sh.tr;
-#pragma unroll
-    for (int i = 0; i < 32; ++i) tr[i * KFH_TRACK_THREADS + threadIdx.x] = acc[i];
-    if (blockIdx.x == 0) icp_store_state(out, sh, gridDim.x, a.level, a.last_iter);
     __syncthreads();
-    {
-        constexpr int PARTS = KFH_TRACK_THREADS / 32;     // threads that share one value (8 or 16)
-        static_assert(PARTS == 8 || PARTS == 16, "block reduction expects 256 or 512 threads");
-        const int v = threadIdx.x / PARTS, part = threadIdx.x % PARTS;
-        const float *src = tr + v * KFH_TRACK_THREADS + part * 32;
-        float sum = 0.f;
+    if (wave == 0) {
+        if (lane < 32) {
+            float t = sh.part[0][lane];
 #pragma unroll
-        for (int k = 0; k < 32; ++k) sum += src[(k + part) & 31];
-        sum = dpp_add<0xB1, 0xF>(sum);    // quad_perm [1,0,3,2]
-        sum = dpp_add<0x4E, 0xF>(sum);    // quad_perm [2,3,0,1]
-        sum = dpp_add<0x114, 0xF>(sum);   // row_shr:4 -> lanes 7 and 15 of a row hold 8-lane sums
-        if (PARTS == 16) sum = dpp_add<0x118, 0xF>(sum);   // row_shr:8 -> lane 15 holds the 16-lane sum
-        KFH_STAMP(4);
-        if (part == PARTS - 1) a.partials_out[blockIdx.x * 32 + v] = sum;
+            for (int w = 1; w < KFH_TRACK_PIXEL_WAVES; ++w) t += sh.part[w][lane];
+            a.partials_out[blockIdx.x * 32 + lane] = t;
+        }
+        if (blockIdx.x == 0) icp_store_state(out, sh, gridDim.x, a.level, a.last_iter);
     }
-    KFH_STAMP(5);
+    KFH_STAMP(6, 0);
 }
 
-hipError_t launch_icp_iteration(const IcpIterArgs &a, hipStream_t s) {
-    const int nb = track_blocks(a.iw, a.ih);
-    if (a.stamps)
-        hipLaunchKernelGGL(k_icp_iteration<true>, dim3(nb), dim3(KFH_TRACK_THREADS), 0, s, a);
-    else
-        hipLaunchKernelGGL(k_icp_iteration<false>, dim3(nb), dim3(KFH_TRACK_THREADS), 0, s, a);
+// largest float d2 with sqrtf(d2) <= t  (sqrtf is monotonic and correctly rounded on host and device)
+static float max_arg_with_sqrt_le(float t) {
+    if (!(t >= 0.f)) return -1.f;
+    float c = t * t;
+    while (sqrtf(c) > t) c = nextafterf(c, 0.f);
+    while (sqrtf(nextafterf(c, INFINITY)) <= t) c = nextafterf(c, INFINITY);
+    return c;
+}
+
+template <bool PACKED>
+static void launch_icp_ppt(const IcpIterArgs &a, int ppt, int nb, hipStream_t s) {
+    const dim3 g(nb), b(KFH_TRACK_THREADS);
+    switch (ppt) {
+        case 1: hipLaunchKernelGGL((k_icp_iteration<PACKED, 1>), g, b, 0, s, a); break;
+        case 2: hipLaunchKernelGGL((k_icp_iteration<PACKED, 2>), g, b, 0, s, a); break;
+        case 3: hipLaunchKernelGGL((k_icp_iteration<PACKED, 3>), g, b, 0, s, a); break;
+        case 5: hipLaunchKernelGGL((k_icp_iteration<PACKED, 5>), g, b, 0, s, a); break;
+        default: hipLaunchKernelGGL((k_icp_iteration<PACKED, 8>), g, b, 0, s, a); break;
+    }
+}
+
+hipError_t launch_icp_iteration(const IcpIterArgs &a_in, hipStream_t s) {
+    IcpIterArgs a = a_in;
+    const bool packed = a.ref_vertex == nullptr;
+    if (packed && (a.in_normal != nullptr || a.ref_tn == nullptr || a.track_out != nullptr)) return hipErrorInvalidValue;
+    if (!packed && (a.in_normal == nullptr || a.ref_normal == nullptr)) return hipErrorInvalidValue;
+    if (a.ppt == 0) a.ppt = track_ppt(a.iw, a.ih, a.max_blocks > 0 ? a.max_blocks : 256);
+    if (a.ppt != 1 && a.ppt != 2 && a.ppt != 3 && a.ppt != 5 && a.ppt != 8) return hipErrorInvalidValue;
+    a.dist2_max = max_arg_with_sqrt_le(a.dist_threshold);
+    {
+        const Mat4 ik = inverse_camera_matrix(a.k[0], a.k[1], a.k[2], a.k[3]);
+        a.ik[0] = ik.m[0]; a.ik[1] = ik.m[2]; a.ik[2] = ik.m[5]; a.ik[3] = ik.m[6];
+    }
+    const int nb = track_blocks(a.iw, a.ih, a.ppt);
+    if (packed) launch_icp_ppt<true>(a, a.ppt, nb, s);
+    else launch_icp_ppt<false>(a, a.ppt, nb, s);
     return hipGetLastError();
 }
 
 // Last launch of tracking: finalise the last iteration, then checkPoseKernel and the derived matrices.
-__global__ __launch_bounds__(KFH_TRACK_THREADS) void k_icp_finish(FinishArgs a) {
-    __shared__ IcpShared sh;
+__global__ __launch_bounds__(KFH_SUM_THREADS) void k_icp_finish(FinishArgs a) {
+    __shared__ float slots[KFH_SUM_THREADS * 4];
+    __shared__ float sums[32];
+    __shared__ Mat4 pose;
+    __shared__ int done_mask, iterations, slow_solves;
     Ctrl *c = a.ctrl;
-    icp_finalize_pending(&c->icp[a.seq & 1], a.partials_in, a.icp_threshold, sh);
+    const IcpState *in = &c->icp[a.seq & 1];
+    PartialRows<KFH_SUM_THREADS> pr;
+    load_partial_rows<KFH_SUM_THREADS>(pr, a.partials_in, a.pending_rows);
+    const int pend = in->pending_nblocks;
+    const Mat4 pose_in = in->pose;
+    if (pend > 0) stage_partial_rows<KFH_SUM_THREADS>(slots, pr, a.partials_in, pend);
+    __syncthreads();
+    if (threadIdx.x >= 64) return;
+    icp_finalize_wave0<KFH_SUM_THREADS>(in, pose_in, pend, a.icp_threshold, slots, sums, &pose, &done_mask, &iterations,
+                                        &slow_solves);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     if (threadIdx.x == 0) {
-        c->pose = sh.pose;
-        for (int i = 0; i < 32; ++i) c->sums[i] = sh.red[i];
-        finish_tracking(a, true, sh.iterations, sh.slow_solves);
+        c->pose = pose;
+        for (int i = 0; i < 32; ++i) c->sums[i] = sums[i];
+        finish_tracking(a, true, iterations, slow_solves);
     }
 }
 
 hipError_t launch_icp_finish(const FinishArgs &a, hipStream_t s) {
-    hipLaunchKernelGGL(k_icp_finish, dim3(1), dim3(KFH_TRACK_THREADS), 0, s, a);
+    hipLaunchKernelGGL(k_icp_finish, dim3(1), dim3(KFH_SUM_THREADS), 0, s, a);
     return hipGetLastError();
 }
 
@@ -793,6 +1191,10 @@ hipError_t launch_track_reduce(Ctrl *scratch_ctrl, float *partials, float *sums,
     a.ctrl = scratch_ctrl;
     a.partials_in = partials;
     a.partials_out = partials;
+    a.pending_rows = 0;
+    a.ref_tn = nullptr;
+    a.ppt = track_ppt(iw, ih, 256);
+    a.max_blocks = 256;
     a.seq = 0;
     a.level = 0;
     a.last_iter = 1;
@@ -805,7 +1207,7 @@ hipError_t launch_track_reduce(Ctrl *scratch_ctrl, float *partials, float *sums,
     a.stamps = nullptr;
     hipError_t e = launch_icp_iteration(a, s);
     if (e != hipSuccess) return e;
-    return launch_sum_partials(sums, partials, track_blocks(iw, ih), s);
+    return launch_sum_partials(sums, partials, track_blocks(iw, ih, a.ppt), s);
 }
 
 __global__ void k_update_pose(float *pose16, double *x6, int *converged, const float *sums, float thr) {
@@ -852,16 +1254,6 @@ constexpr int INTEGRATE_UNROLL = 8;
 // This is the instruction sequence of the compiler's own IEEE division (reciprocal estimate, one Newton
 // step, two quotient corrections) without the exponent pre-scaling, which only matters for operands near
 // the ends of the float range; the integrate kernel divides metres and pixels by a depth >= 1e-4.
-__device__ inline float refined_rcp(float d) {
-    const float r = __builtin_amdgcn_rcpf(d);
-    return fmaf(fmaf(-d, r, 1.f), r, r);
-}
-__device__ inline float div_shared(float n, float d, float r1) {
-    const float q0 = n * r1;
-    const float q1 = fmaf(fmaf(-d, q0, n), r1, q0);
-    return fmaf(fmaf(-d, q1, n), r1, q1);
-}
-
 __global__ __launch_bounds__(256) void k_integrate(short2 *__restrict__ vol, int sx, int sy, int sz,
                                                    float dimx, float dimy, float dimz, int z0, int z1,
                                                    const float *__restrict__ depth, int w, int h,
@@ -1173,7 +1565,8 @@ struct VolDev {
 
 template <bool POW2>
 __global__ __launch_bounds__(256, 5) void k_raycast(float4 *__restrict__ vertex, float4 *__restrict__ normal,
-                                                 float *__restrict__ ray_t, int w, int h, VolDev<POW2> vol,
+                                                 float *__restrict__ ray_t, float4 *__restrict__ ref_tn, int w,
+                                                 int h, VolDev<POW2> vol,
                                                  float zc0, float zc1, const Mat4 *__restrict__ view_p,
                                                  float near_plane, float far_plane, float step,
                                                  float largestep) {
@@ -1313,24 +1706,24 @@ __global__ __launch_bounds__(256, 5) void k_raycast(float4 *__restrict__ vertex,
     }
     if (!inside) return;
     const int o = x + y * w;
+    float4 nrm = make_float4(KFH_INVALID, 0.f, 0.f, 0.f);
     if (hit.w > 0.0f) {
-        vertex[o] = make_float4(hit.x, hit.y, hit.z, 0.f);
         const f3 g = vol.grad(mk3(hit.x, hit.y, hit.z));
-        if (length3(g) == 0) {
-            normal[o] = make_float4(KFH_INVALID, 0.f, 0.f, 0.f);
-        } else {
+        if (length3(g) != 0) {
             const f3 n = normalize3(g);
-            normal[o] = make_float4(n.x, n.y, n.z, 0.f);
+            nrm = make_float4(n.x, n.y, n.z, 0.f);
         }
-    } else {
-        vertex[o] = make_float4(0.f, 0.f, 0.f, 0.f);
-        normal[o] = make_float4(KFH_INVALID, 0.f, 0.f, 0.f);
     }
+    vertex[o] = make_float4(hit.x, hit.y, hit.z, 0.f);
+    normal[o] = nrm;
+    // packed model map for tracking: hit distance + normal (the vertex is origin + direction * t)
+    if (ref_tn) ref_tn[o] = make_float4(hit.w, nrm.x, nrm.y, nrm.z);
     if (ray_t) ray_t[o] = hit.w;
 }
 
 template <bool POW2>
-static hipError_t launch_raycast_t(float4 *vertex, float4 *normal, float *ray_t, int w, int h, const short2 *vol,
+static hipError_t launch_raycast_t(float4 *vertex, float4 *normal, float *ray_t, float4 *ref_tn, int w, int h,
+                                   const short2 *vol,
                                    const int res[3], const float dim[3], int z0, int z1, const Mat4 *view,
                                    float near_plane, float far_plane, float step, float largestep,
                                    hipStream_t s) {
@@ -1352,12 +1745,13 @@ static hipError_t launch_raycast_t(float4 *vertex, float4 *normal, float *ray_t,
         zc1 = (float)(z1 < res[2] ? z1 + 1 : z1) * (dim[2] / (float)res[2]);
     }
     const dim3 grid((w + 15) / 16, (h + 15) / 16);
-    hipLaunchKernelGGL(k_raycast<POW2>, grid, dim3(256), 0, s, vertex, normal, ray_t, w, h, v, zc0, zc1, view,
+    hipLaunchKernelGGL(k_raycast<POW2>, grid, dim3(256), 0, s, vertex, normal, ray_t, ref_tn, w, h, v, zc0, zc1, view,
                        near_plane, far_plane, step, largestep);
     return hipGetLastError();
 }
 
-hipError_t launch_raycast(float4 *vertex, float4 *normal, float *ray_t, int w, int h, const short2 *vol,
+hipError_t launch_raycast(float4 *vertex, float4 *normal, float *ray_t, float4 *ref_tn, int w, int h,
+                          const short2 *vol,
                           const int res[3], const float dim[3], int z0, int z1, const Mat4 *view,
                           float near_plane, float far_plane, float step, float largestep, hipStream_t s) {
     bool pow2 = true;
@@ -1367,15 +1761,16 @@ hipError_t launch_raycast(float4 *vertex, float4 *normal, float *ray_t, int w, i
         const bool res_pow2 = (res[i] & (res[i] - 1)) == 0;
         if (!dim_pow2 || !res_pow2 || res[i] < 2) pow2 = false;
     }
-    return pow2 ? launch_raycast_t<true>(vertex, normal, ray_t, w, h, vol, res, dim, z0, z1, view, near_plane,
+    return pow2 ? launch_raycast_t<true>(vertex, normal, ray_t, ref_tn, w, h, vol, res, dim, z0, z1, view, near_plane,
                                          far_plane, step, largestep, s)
-                : launch_raycast_t<false>(vertex, normal, ray_t, w, h, vol, res, dim, z0, z1, view, near_plane,
+                : launch_raycast_t<false>(vertex, normal, ray_t, ref_tn, w, h, vol, res, dim, z0, z1, view, near_plane,
                                           far_plane, step, largestep, s);
 }
 
 // Per pixel, keep the slab candidate with the smallest positive hit distance.
 __global__ __launch_bounds__(256) void k_composite(float4 *__restrict__ vertex, float4 *__restrict__ normal,
-                                                   float *__restrict__ ray_t, const float *__restrict__ t_parts,
+                                                   float *__restrict__ ray_t, float4 *__restrict__ ref_tn,
+                                                   const float *__restrict__ t_parts,
                                                    const float4 *__restrict__ v_parts,
                                                    const float4 *__restrict__ n_parts, int n, int npix) {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1386,19 +1781,20 @@ __global__ __launch_bounds__(256) void k_composite(float4 *__restrict__ vertex, 
         const float t = t_parts[(size_t)i * npix + p];
         if (t > 0.f && (arg < 0 || t < best)) { best = t; arg = i; }
     }
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f), nrm = make_float4(KFH_INVALID, 0.f, 0.f, 0.f);
     if (arg >= 0) {
-        vertex[p] = v_parts[(size_t)arg * npix + p];
-        normal[p] = n_parts[(size_t)arg * npix + p];
-    } else {
-        vertex[p] = make_float4(0.f, 0.f, 0.f, 0.f);
-        normal[p] = make_float4(KFH_INVALID, 0.f, 0.f, 0.f);
+        v = v_parts[(size_t)arg * npix + p];
+        nrm = n_parts[(size_t)arg * npix + p];
     }
+    vertex[p] = v;
+    normal[p] = nrm;
+    if (ref_tn) ref_tn[p] = make_float4(best, nrm.x, nrm.y, nrm.z);
     if (ray_t) ray_t[p] = best;
 }
 
-hipError_t launch_composite(float4 *vertex, float4 *normal, float *ray_t, const float *t_parts,
+hipError_t launch_composite(float4 *vertex, float4 *normal, float *ray_t, float4 *ref_tn, const float *t_parts,
                             const float4 *v_parts, const float4 *n_parts, int n, int npix, hipStream_t s) {
-    hipLaunchKernelGGL(k_composite, dim3((npix + 255) / 256), dim3(256), 0, s, vertex, normal, ray_t, t_parts,
+    hipLaunchKernelGGL(k_composite, dim3((npix + 255) / 256), dim3(256), 0, s, vertex, normal, ray_t, ref_tn, t_parts,
                        v_parts, n_parts, n, npix);
     return hipGetLastError();
 }

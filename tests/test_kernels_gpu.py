@@ -222,7 +222,7 @@ def _update_pose_gpu(torch, L, pose, sums, thr=1e-5):
     native.check(L.kfh_k_update_pose(vp(p), vp(x), vp(conv), vp(s), thr, None))
     torch.cuda.synchronize()
     conv = conv.cpu().numpy()
-    return p.cpu().numpy().reshape(4, 4), x.cpu().numpy(), bool(conv[0]), bool(conv[1])
+    return p.cpu().numpy().reshape(4, 4), x.cpu().numpy(), bool(conv[0]), int(conv[1])
 
 
 def test_update_pose_well_conditioned(torch_cuda, L, scene):
@@ -261,8 +261,49 @@ def test_update_pose_rank_deficient(torch_cuda, L):
     assert np.abs(x_want).max() < 1.0          # the cut-off keeps the update finite
     pose_want, conv_want = kf_ref.update_pose(pose, sums)
     pose_got, x_got, conv_got, slow = _update_pose_gpu(torch_cuda, L, pose, sums)
-    assert slow
+    assert slow == 1                            # full eigen-decomposition
     np.testing.assert_allclose(x_got, x_want, rtol=1e-6, atol=1e-10)
+    np.testing.assert_allclose(pose_got, pose_want, rtol=0, atol=1e-6)
+    assert conv_got == conv_want
+
+
+def _system_with_spectrum(eigs, seed):
+    """sums[1:28] of a normal-equation system C x = b with the given eigenvalues of C and b in its range."""
+    rng = np.random.default_rng(seed)
+    q, _ = np.linalg.qr(rng.standard_normal((6, 6)))
+    C = (q * np.asarray(eigs, np.float64)) @ q.T
+    C = 0.5 * (C + C.T)
+    b = C @ rng.standard_normal(6) + 1e-6 * np.abs(eigs).max() * q[:, 0]   # plus a little along the weakest axis
+    sums = np.zeros(32, np.float32)
+    sums[0] = 1.0
+    sums[1:7] = b
+    k = 7
+    for i in range(6):
+        for j in range(i, 6):
+            sums[k] = C[i, j]
+            k += 1
+    sums[28] = 1000
+    return sums
+
+
+@pytest.mark.parametrize("case,eigs,paths", [
+    ("well inside", [4.0, 40.0, 300.0, 5e3, 2e5, 1.8e6], (0,)),          # cond 0.45e6: certified by the norms
+    ("just dropped", [1.5, 40.0, 300.0, 5e3, 2e5, 2.2e6], (2,)),         # cond 1.5e6: the smallest is dropped
+    ("far dropped", [0.02, 40.0, 300.0, 5e3, 2e5, 2.2e6], (2,)),         # cond 1.1e8
+    ("two dropped", [1.0, 1.4, 300.0, 5e3, 2e5, 2.2e6], (1,)),           # needs the full decomposition
+    ("cluster kept", [2.6, 2.8, 3.0, 5e3, 2e5, 1.8e6], (0, 1)),          # cond 0.7e6, norms inconclusive
+])
+def test_update_pose_near_conditioning_limit(torch_cuda, L, case, eigs, paths):
+    """Systems around the sigma_max / 1e6 cut-off: which path the device takes, and that every path
+    reproduces the reference's truncated solution (the float-rounded sums decide the spectrum, so the
+    expectation is taken from the oracle on the same 27 floats)."""
+    sums = _system_with_spectrum(eigs, seed=3)
+    pose = np.eye(4, dtype=np.float32)
+    x_want = kf_ref.solve(sums[1:28])
+    pose_want, conv_want = kf_ref.update_pose(pose, sums)
+    pose_got, x_got, conv_got, slow = _update_pose_gpu(torch_cuda, L, pose, sums)
+    assert slow in paths, (case, slow)
+    np.testing.assert_allclose(x_got, x_want, rtol=1e-6, atol=1e-9 * np.abs(x_want).max())
     np.testing.assert_allclose(pose_got, pose_want, rtol=0, atol=1e-6)
     assert conv_got == conv_want
 
