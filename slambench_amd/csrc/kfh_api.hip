@@ -69,6 +69,8 @@ struct kfh_context {
     float4 *d_in_vertex[3] = {nullptr, nullptr, nullptr};
     float4 *d_in_normal[3] = {nullptr, nullptr, nullptr};
     float4 *d_vertex = nullptr, *d_normal = nullptr;
+    unsigned *d_integrate_boxes = nullptr; // boxes the integrate plan launch kept for the work launch
+    void *d_ray_tasks = nullptr;           // rays handed from the first raycast pass to the second
     float4 *d_ref_tn = nullptr;            // packed model map {hit distance, normal}: what tracking gathers
     float *d_ray_t = nullptr;
     int depth_version = 0;                 // bumped whenever the depth pyramid changes
@@ -121,7 +123,7 @@ void free_all(kfh_context *c) {
     if (c->h_depth_pinned) (void)hipHostFree(c->h_depth_pinned);
     void *bufs[] = {c->d_depth_in, c->d_float_depth, c->d_scaled[0], c->d_scaled[1], c->d_scaled[2],
                     c->d_in_vertex[0], c->d_in_vertex[1], c->d_in_vertex[2], c->d_in_normal[0],
-                    c->d_in_normal[1], c->d_in_normal[2], c->d_vertex, c->d_normal, c->d_ray_t, c->d_volume, c->d_ref_tn,
+                    c->d_in_normal[1], c->d_in_normal[2], c->d_vertex, c->d_normal, c->d_ray_t, c->d_volume, c->d_ref_tn, c->d_ray_tasks, c->d_integrate_boxes,
                     c->d_partials, c->d_ctrl, c->d_status, c->d_stamps};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
@@ -228,6 +230,9 @@ int kfh_create(const kfh_config *cfg, kfh_context **out) {
     if (e == hipSuccess) e = dev_alloc(&c->d_normal, npix);
     if (e == hipSuccess) e = dev_alloc(&c->d_ray_t, npix);
     if (e == hipSuccess) e = dev_alloc(&c->d_ref_tn, npix);
+    if (e == hipSuccess) e = hipMalloc(&c->d_ray_tasks, raycast_task_bytes(c->w, c->h));
+    if (e == hipSuccess)
+        e = hipMalloc(reinterpret_cast<void **>(&c->d_integrate_boxes), integrate_box_list_bytes(cfg->vol_res, c->zs1));
     if (e == hipSuccess) e = dev_alloc(&c->d_volume, c->volume_voxels);
     {
         hipDeviceProp_t prop;
@@ -358,7 +363,8 @@ int kfh_integrate(kfh_context *c) {
         // planes [zs0, zs1) are stored; the kernel replays the z < zs0 steps of each column arithmetically
         KFH_HIP(launch_integrate(c->d_volume, c->cfg.vol_res, c->cfg.vol_dim, c->zs0, c->zs1, src, c->w, c->h,
                                  &c->d_ctrl->inv_pose, camera_matrix(c->k[0], c->k[1], c->k[2], c->k[3]),
-                                 c->cfg.mu, MAX_WEIGHT, &c->d_ctrl->integrate_gate, c->stream));
+                                 c->cfg.mu, MAX_WEIGHT, &c->d_ctrl->integrate_gate, c->d_integrate_boxes,
+                                 &c->d_ctrl->integrate_box_count, c->stream));
     }
     if (c->timing) {
         KFH_HIP(hipEventRecord(c->ev[c->frame % KFH_TIMING_RING][3], c->stream));
@@ -380,7 +386,8 @@ int kfh_raycast(kfh_context *c) {
     if (c->frame > 2 && !c->sharded) {
         KFH_HIP(launch_raycast(c->d_vertex, c->d_normal, c->d_ray_t, c->d_ref_tn, c->w, c->h, c->d_volume,
                                c->cfg.vol_res, c->cfg.vol_dim, 0, c->cfg.vol_res[2], &c->d_ctrl->view, NEAR_PLANE, FAR_PLANE,
-                               raycast_step(c->cfg), 0.75f * c->cfg.mu, c->stream));
+                               raycast_step(c->cfg), 0.75f * c->cfg.mu, c->d_ray_tasks,
+                               &c->d_ctrl->ray_task_count, c->stream));
     }
     if (c->timing == 1) {
         KFH_HIP(hipEventRecord(c->ev[c->frame % KFH_TIMING_RING][4], c->stream));
@@ -394,7 +401,8 @@ int kfh_raycast_slab(kfh_context *c) {
     if (c->frame > 2) {
         KFH_HIP(launch_raycast(c->d_vertex, c->d_normal, c->d_ray_t, nullptr, c->w, c->h, c->d_volume,
                                c->cfg.vol_res, c->cfg.vol_dim, c->cfg.slab_z0, c->cfg.slab_z1, &c->d_ctrl->view, NEAR_PLANE,
-                               FAR_PLANE, raycast_step(c->cfg), 0.75f * c->cfg.mu, c->stream));
+                               FAR_PLANE, raycast_step(c->cfg), 0.75f * c->cfg.mu, c->d_ray_tasks,
+                               &c->d_ctrl->ray_task_count, c->stream));
     }
     return KFH_OK;
 }
@@ -550,6 +558,57 @@ int kfh_phase_ms(kfh_context *c, float ms[4]) {
     return kfh_phase_ms_frame(c, c->frame - 1, ms);
 }
 
+// Diagnostic (not part of include/kfusion_hip.h): fuse the current depth map once more (this changes the
+// volume) with per-wavefront records {start tick, end tick, candidate voxels, voxels written}.
+// h_out holds n_values = boxes * 4 wavefronts * 4 values + 1; the last one receives the number of boxes kept.
+int kfh_debug_integrate_stats(kfh_context *c, unsigned long long *h_out, size_t n_values) {
+    KFH_REQUIRE(c != nullptr && h_out != nullptr, "NULL argument");
+    unsigned long long *d = nullptr;
+    KFH_HIP(hipMalloc(reinterpret_cast<void **>(&d), n_values * sizeof(unsigned long long)));
+    KFH_HIP(hipMemset(d, 0, n_values * sizeof(unsigned long long)));
+    KFH_HIP(hipMemsetAsync(&c->d_ctrl->integrate_box_count, 0, sizeof(unsigned), c->stream));
+    set_integrate_debug(d);
+    const float *src = c->cfg.integrate_filtered ? c->d_scaled[0] : c->d_float_depth;
+    hipError_t e = launch_integrate(c->d_volume, c->cfg.vol_res, c->cfg.vol_dim, c->zs0, c->zs1, src, c->w, c->h,
+                                    &c->d_ctrl->inv_pose, camera_matrix(c->k[0], c->k[1], c->k[2], c->k[3]),
+                                    c->cfg.mu, MAX_WEIGHT, nullptr, c->d_integrate_boxes,
+                                    &c->d_ctrl->integrate_box_count, c->stream);
+    set_integrate_debug(nullptr);
+    if (e == hipSuccess) e = hipMemcpyAsync(h_out + n_values - 1, &c->d_ctrl->integrate_box_count, sizeof(unsigned),
+                                            hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess) e = hipMemcpy(h_out, d, (n_values - 1) * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    KFH_HIP(e);
+    return KFH_OK;
+}
+
+// Diagnostic (not part of include/kfusion_hip.h): run the raycast of the current state once more with
+// per-wavefront records {start tick, end tick, batches, tail rounds} (100 MHz ticks) and copy them out.
+// h_out holds ((w+15)/16) * ((h+15)/16) * 4 wavefronts * 4 values, then one more: the number of rays the
+// second pass received.
+int kfh_debug_raycast_stats(kfh_context *c, unsigned long long *h_out) {
+    KFH_REQUIRE(c != nullptr && h_out != nullptr, "NULL argument");
+    const size_t n = (size_t)((c->w + 15) / 16) * ((c->h + 15) / 16) * 16;
+    unsigned long long *d = nullptr;
+    KFH_HIP(hipMalloc(reinterpret_cast<void **>(&d), n * sizeof(unsigned long long)));
+    KFH_HIP(hipMemset(d, 0, n * sizeof(unsigned long long)));
+    KFH_HIP(hipMemsetAsync(&c->d_ctrl->ray_task_count, 0, sizeof(unsigned), c->stream));
+    set_raycast_debug(d);
+    hipError_t e = launch_raycast(c->d_vertex, c->d_normal, c->d_ray_t, c->d_ref_tn, c->w, c->h, c->d_volume,
+                                  c->cfg.vol_res, c->cfg.vol_dim, 0, c->cfg.vol_res[2], &c->d_ctrl->view, NEAR_PLANE,
+                                  FAR_PLANE, raycast_step(c->cfg), 0.75f * c->cfg.mu, c->d_ray_tasks,
+                                  &c->d_ctrl->ray_task_count, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(h_out + n, &c->d_ctrl->ray_task_count, sizeof(unsigned),
+                                            hipMemcpyDeviceToHost, c->stream);
+    set_raycast_debug(nullptr);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess) e = hipMemcpy(h_out, d, n * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    KFH_HIP(e);
+    return KFH_OK;
+}
+
 // Diagnostic (not part of include/kfusion_hip.h): copy the ICP time stamps of the last frame,
 // [64 launches][320 blocks][8 slots] ticks of the 100 MHz real-time counter.  Only filled when the context
 // was created with KFH_ICP_STAMPS set.
@@ -640,16 +699,20 @@ int kfh_k_integrate(void *d_volume, const int32_t res[3], const float dim[3], in
     KFH_REQUIRE(res[0] > 0 && res[1] > 0 && res[2] > 0 && 0 <= z0 && z0 < z1 && z1 <= res[2], "bad volume range");
     KFH_REQUIRE(w > 0 && h > 0 && mu > 0.f, "bad argument");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    Mat4 *d_inv = nullptr;
-    KFH_HIP(hipMalloc(reinterpret_cast<void **>(&d_inv), sizeof(Mat4)));
+    // scratch: [inverse pose | box counter | box list]
+    char *scratch = nullptr;
+    KFH_HIP(hipMalloc(reinterpret_cast<void **>(&scratch), 512 + integrate_box_list_bytes(res, z1)));
+    Mat4 *d_inv = reinterpret_cast<Mat4 *>(scratch);
+    unsigned *d_count = reinterpret_cast<unsigned *>(scratch + 256);
     Mat4 Km;
     std::memcpy(Km.m, K, sizeof(Km.m));
     hipError_t e = hipMemcpyAsync(d_inv, invTrack, sizeof(Mat4), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemsetAsync(d_count, 0, sizeof(unsigned), s);
     if (e == hipSuccess)
         e = launch_integrate(static_cast<short2 *>(d_volume), res, dim, z0, z1, d_depth, w, h, d_inv, Km, mu,
-                             maxweight, nullptr, s);
+                             maxweight, nullptr, reinterpret_cast<unsigned *>(scratch + 512), d_count, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
-    (void)hipFree(d_inv);
+    (void)hipFree(scratch);
     KFH_HIP(e);
     return KFH_OK;
 }
@@ -661,15 +724,19 @@ int kfh_k_raycast(void *d_vertex4, void *d_normal4, int w, int h, const void *d_
     KFH_REQUIRE(w > 0 && h > 0 && res[0] > 0 && res[1] > 0 && res[2] > 0, "bad sizes");
     KFH_REQUIRE(step > 0.f && largestep > 0.f, "steps must be positive");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    Mat4 *d_view = nullptr;
-    KFH_HIP(hipMalloc(reinterpret_cast<void **>(&d_view), sizeof(Mat4)));
+    // scratch: [view matrix | task counter | task list]
+    char *scratch = nullptr;
+    KFH_HIP(hipMalloc(reinterpret_cast<void **>(&scratch), 512 + raycast_task_bytes(w, h)));
+    Mat4 *d_view = reinterpret_cast<Mat4 *>(scratch);
+    unsigned *d_count = reinterpret_cast<unsigned *>(scratch + 256);
     hipError_t e = hipMemcpyAsync(d_view, view, sizeof(Mat4), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemsetAsync(d_count, 0, sizeof(unsigned), s);
     if (e == hipSuccess)
         e = launch_raycast(static_cast<float4 *>(d_vertex4), static_cast<float4 *>(d_normal4), nullptr, nullptr, w, h,
                            static_cast<const short2 *>(d_volume), res, dim, 0, res[2], d_view, near_plane,
-                           far_plane, step, largestep, s);
+                           far_plane, step, largestep, scratch + 512, d_count, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
-    (void)hipFree(d_view);
+    (void)hipFree(scratch);
     KFH_HIP(e);
     return KFH_OK;
 }

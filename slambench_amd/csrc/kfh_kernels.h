@@ -34,7 +34,9 @@ struct Ctrl {
     int tracked;        // result of the pose check of this frame
     int integrate_gate; // this frame fuses its depth map: (tracked and rate hit) or frame <= 3
     int frame;          // frame counter (device copy)
-    int pad_;
+    unsigned ray_task_count;  // rays the first raycast pass handed to the second (reset by the tracking finish)
+    unsigned integrate_box_count;  // boxes the integrate plan launch kept (reset by the tracking finish)
+    int pad_[3];
     IcpState icp[2];    // alternating records of the ICP loop
 };
 
@@ -121,15 +123,26 @@ hipError_t launch_sum_partials(float *sums, const float *partials, int nrows, hi
 hipError_t launch_update_pose(float *pose16, double *x6, int *converged, const float *sums, float thr,
                               hipStream_t s);
 hipError_t launch_pose_derive(Ctrl *ctrl, const float k[4], int set_raycast_pose, hipStream_t s);
+// Two launches: a plan launch lists the 64 x 4 x zchunk boxes that can touch the camera frustum, the work launch
+// fuses the depth map into those.  `boxes` holds integrate_box_list_bytes() bytes and *box_count must be zero
+// when the first launch starts.
+size_t integrate_box_list_bytes(const int res[3], int z1);
 hipError_t launch_integrate(short2 *vol, const int res[3], const float dim[3], int z0, int z1,
                             const float *depth, int w, int h, const Mat4 *inv_track, Mat4 K, float mu,
-                            float maxweight, const int *gate, hipStream_t s);
-hipError_t launch_raycast(float4 *vertex, float4 *normal, float *ray_t, float4 *ref_tn, int w, int h, const short2 *vol,
-                          const int res[3], const float dim[3], int z0, int z1, const Mat4 *view,
-                          float near_plane, float far_plane, float step, float largestep, hipStream_t s);
+                            float maxweight, const int *gate, unsigned *boxes, unsigned *box_count, hipStream_t s);
+// Two launches: per-pixel march, then the rays it left unfinished.  `tasks` holds raycast_task_bytes(w, h)
+// bytes and *task_count must be zero when the first launch starts.
+size_t raycast_task_bytes(int w, int h);
+hipError_t launch_raycast(float4 *vertex, float4 *normal, float *ray_t, float4 *ref_tn, int w, int h,
+                          const short2 *vol, const int res[3], const float dim[3], int z0, int z1, const Mat4 *view,
+                          float near_plane, float far_plane, float step, float largestep, void *tasks,
+                          unsigned *task_count, hipStream_t s);
 hipError_t launch_composite(float4 *vertex, float4 *normal, float *ray_t, float4 *ref_tn, const float *t_parts,
                             const float4 *v_parts, const float4 *n_parts, int n_parts_count, int npix,
                             hipStream_t s);
+// diagnostics: per-wavefront records of every following raycast launch go to d_buffer (null: off)
+void set_raycast_debug(unsigned long long *d_buffer);
+void set_integrate_debug(unsigned long long *d_buffer);
 hipError_t launch_fill_volume(short2 *vol, size_t nvox, hipStream_t s);
 
 }  // namespace kfh

@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <cstdlib>
 
 namespace kfh {
 
@@ -631,6 +632,8 @@ __device__ void finish_tracking(const FinishArgs &a, bool ran_tracking, int iter
         }
     }
     c->tracked = tracked;
+    c->ray_task_count = 0;      // the raycast of this frame appends its unfinished rays from here
+    c->integrate_box_count = 0; // likewise the box list of this frame's integration
     const int integrated = ((tracked && (a.frame % a.integration_rate) == 0) || a.frame <= 3) ? 1 : 0;
     c->integrate_gate = integrated;
     c->frame = a.frame;
@@ -1254,160 +1257,248 @@ constexpr int INTEGRATE_UNROLL = 8;
 // This is the instruction sequence of the compiler's own IEEE division (reciprocal estimate, one Newton
 // step, two quotient corrections) without the exponent pre-scaling, which only matters for operands near
 // the ends of the float range; the integrate kernel divides metres and pixels by a depth >= 1e-4.
-__global__ __launch_bounds__(256) void k_integrate(short2 *__restrict__ vol, int sx, int sy, int sz,
-                                                   float dimx, float dimy, float dimz, int z0, int z1,
-                                                   const float *__restrict__ depth, int w, int h,
-                                                   const Mat4 *__restrict__ inv_track_p, Mat4 K, float mu,
-                                                   float maxweight, const int *__restrict__ gate, int zchunk) {
-    if (gate && *gate == 0) return;
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x >= sx || y >= sy) return;
-    // blockIdx.z selects a z chunk of the column; the steps below it are replayed arithmetically
-    const int zc0 = max(z0, (int)blockIdx.z * zchunk);
-    const int zc1 = min(z1, ((int)blockIdx.z + 1) * zchunk);
-    if (zc0 >= zc1) return;
-    const Mat4 invTrack = *inv_track_p;
-    const float wmax = (float)(w - 1), hmax = (float)(h - 1);
-    {
-        // Conservative frustum culling of this block's 64 x 4 x zchunk box, grown by two voxels per side.
-        // A voxel is only ever touched if it passes the half-space tests of the march below; if all eight
-        // corners of the grown box fail the same half-space, no voxel of the block can pass it (the two
-        // voxels of slack are far more than the drift of the incrementally accumulated positions), and the
-        // block leaves without replaying the column prefix.
-        const float vx = dimx / (float)sx, vy = dimy / (float)sy, vz = dimz / (float)sz;
-        const float bx0 = ((float)((int)blockIdx.x * 64 - 2) + 0.5f) * vx;
-        const float bx1 = ((float)(min((int)blockIdx.x * 64 + 63, sx - 1) + 2) + 0.5f) * vx;
-        const float by0 = ((float)((int)blockIdx.y * 4 - 2) + 0.5f) * vy;
-        const float by1 = ((float)(min((int)blockIdx.y * 4 + 3, sy - 1) + 2) + 0.5f) * vy;
-        const float bz0 = ((float)(zc0 - 2) + 0.5f) * vz;
-        const float bz1 = ((float)(zc1 + 1) + 0.5f) * vz;
-        const f3 c0 = xform(invTrack, mk3(bx0, by0, bz0));
-        const f3 ex = rotate(invTrack, mk3(bx1 - bx0, 0.f, 0.f));
-        const f3 ey = rotate(invTrack, mk3(0.f, by1 - by0, 0.f));
-        const f3 ez = rotate(invTrack, mk3(0.f, 0.f, bz1 - bz0));
-        bool behind = true, left = true, right = true, up = true, down = true;
+struct IntegrateArgs {
+    short2 *vol;
+    int sx, sy, sz;
+    float dimx, dimy, dimz;
+    int z0, z1;                 // stored / owned planes
+    const float *depth;
+    int w, h;
+    const Mat4 *inv_track;
+    Mat4 K;
+    float mu, maxweight;
+    const int *gate;            // device flag: 0 = this frame does not integrate
+    int zchunk;
+    int gx, gy, gz;             // boxes of 64 x 4 x zchunk voxels
+    unsigned *boxes;            // list of boxes that may touch the camera frustum (packed bx | by << 8 | bz << 20)
+    unsigned *box_count;
+    unsigned long long *dbg;
+};
+
+// Conservative frustum culling of the box of 64 x 4 x (zc1 - zc0) voxels at (bx * 64, by * 4, zc0), grown by
+// two voxels per side.  A voxel is only ever touched if it passes the half-space tests of the march; if all
+// eight corners of the grown box fail the same half-space, no voxel of the box can pass it (the two voxels
+// of slack are far more than the drift of the incrementally accumulated positions).
+__device__ inline bool box_misses_frustum(const IntegrateArgs &a, const Mat4 &invTrack, int bx, int by, int zc0,
+                                          int zc1) {
+    const float wmax = (float)(a.w - 1), hmax = (float)(a.h - 1);
+    const float vx = a.dimx / (float)a.sx, vy = a.dimy / (float)a.sy, vz = a.dimz / (float)a.sz;
+    const float bx0 = ((float)(bx * 64 - 2) + 0.5f) * vx;
+    const float bx1 = ((float)(min(bx * 64 + 63, a.sx - 1) + 2) + 0.5f) * vx;
+    const float by0 = ((float)(by * 4 - 2) + 0.5f) * vy;
+    const float by1 = ((float)(min(by * 4 + 3, a.sy - 1) + 2) + 0.5f) * vy;
+    const float bz0 = ((float)(zc0 - 2) + 0.5f) * vz;
+    const float bz1 = ((float)(zc1 + 1) + 0.5f) * vz;
+    const f3 c0 = xform(invTrack, mk3(bx0, by0, bz0));
+    const f3 ex = rotate(invTrack, mk3(bx1 - bx0, 0.f, 0.f));
+    const f3 ey = rotate(invTrack, mk3(0.f, by1 - by0, 0.f));
+    const f3 ez = rotate(invTrack, mk3(0.f, 0.f, bz1 - bz0));
+    bool behind = true, left = true, right = true, up = true, down = true;
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            f3 P = c0;
-            if (q & 1) P = P + ex;
-            if (q & 2) P = P + ey;
-            if (q & 4) P = P + ez;
-            const float cxp = K.m[0] * P.x + K.m[2] * P.z;
-            const float cyp = K.m[5] * P.y + K.m[6] * P.z;
-            behind = behind && (P.z < 0.0001f);
-            left = left && (cxp < -1.5f * P.z);
-            right = right && (cxp > (wmax + 1.5f) * P.z);
-            up = up && (cyp < -1.5f * P.z);
-            down = down && (cyp > (hmax + 1.5f) * P.z);
-        }
-        if (behind || left || right || up || down) return;
+    for (int q = 0; q < 8; ++q) {
+        f3 P = c0;
+        if (q & 1) P = P + ex;
+        if (q & 2) P = P + ey;
+        if (q & 4) P = P + ez;
+        const float cxp = a.K.m[0] * P.x + a.K.m[2] * P.z;
+        const float cyp = a.K.m[5] * P.y + a.K.m[6] * P.z;
+        behind = behind && (P.z < 0.0001f);
+        left = left && (cxp < -1.5f * P.z);
+        right = right && (cxp > (wmax + 1.5f) * P.z);
+        up = up && (cyp < -1.5f * P.z);
+        down = down && (cyp > (hmax + 1.5f) * P.z);
     }
+    return behind || left || right || up || down;
+}
+
+// First launch: one thread per box decides whether the box can touch the frustum and appends the survivors
+// to the list (typically a few percent of the volume).  The work launch then only runs on those, instead
+// of dispatching a workgroup per box of the whole volume.
+__global__ __launch_bounds__(256) void k_integrate_plan(IntegrateArgs a) {
+    if (a.gate && *a.gate == 0) return;
+    const int id = blockIdx.x * blockDim.x + threadIdx.x;
+    const int nbox = a.gx * a.gy * a.gz;
+    bool keep = false;
+    int bx = 0, by = 0, bz = 0;
+    if (id < nbox) {
+        bx = id % a.gx;
+        by = (id / a.gx) % a.gy;
+        bz = id / (a.gx * a.gy);
+        const int zc0 = max(a.z0, bz * a.zchunk), zc1 = min(a.z1, (bz + 1) * a.zchunk);
+        keep = zc0 < zc1 && !box_misses_frustum(a, *a.inv_track, bx, by, zc0, zc1);
+    }
+    const unsigned long long m = __ballot(keep);
+    if (m) {
+        const int lane = threadIdx.x & 63, first = __ffsll((long long)m) - 1;
+        unsigned base = 0;
+        if (lane == first) base = atomicAdd(a.box_count, (unsigned)__popcll(m));
+        base = __builtin_amdgcn_readlane(base, first);
+        if (keep) a.boxes[base + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned)bx | ((unsigned)by << 8) | ((unsigned)bz << 20);
+    }
+}
+
+// Second launch: a workgroup takes boxes from the list; one thread per (x, y) column of the box.
+__global__ __launch_bounds__(256) void k_integrate(IntegrateArgs a) {
+    const unsigned nbox = *a.box_count;
+    if (nbox == 0) return;
+    // diagnostics (dbg != null): per box and wavefront {start, end} of the 100 MHz counter, candidates, written
+    const Mat4 invTrack = *a.inv_track;
+    const int sx = a.sx, sy = a.sy, sz = a.sz, w = a.w;
+    const float dimx = a.dimx, dimy = a.dimy, dimz = a.dimz, mu = a.mu, maxweight = a.maxweight;
+    const Mat4 K = a.K;
+    const float wmax = (float)(a.w - 1), hmax = (float)(a.h - 1);
     const f3 delta = rotate(invTrack, mk3(0, 0, dimz / (float)sz));
     const f3 cameraDelta = rotate(K, delta);
-    const f3 p0 = mk3(((float)x + 0.5f) * dimx / (float)sx, ((float)y + 0.5f) * dimy / (float)sy,
-                      (0.0f + 0.5f) * dimz / (float)sz);
-    f3 pos = xform(invTrack, p0);
-    f3 cameraX = xform(K, pos);
     const size_t plane = (size_t)sx * sy;
-    short2 *col = vol + (size_t)x + (size_t)y * sx;
-    {
-        // replay the additions of the steps below this chunk: same operations in the same order as a march
-        // from z = 0, two components per packed add
-        typedef float v2f __attribute__((ext_vector_type(2)));
-        v2f a0 = {pos.x, pos.y}, a1 = {pos.z, cameraX.x}, a2 = {cameraX.y, cameraX.z};
-        const v2f d0 = {delta.x, delta.y}, d1 = {delta.z, cameraDelta.x}, d2 = {cameraDelta.y, cameraDelta.z};
+    const float *__restrict__ depth = a.depth;
+    for (unsigned bi = blockIdx.x; bi < nbox; bi += gridDim.x) {
+        unsigned long long dbg_t0 = 0;
+        unsigned dbg_cand = 0, dbg_written = 0;
+        if (a.dbg) dbg_t0 = __builtin_amdgcn_s_memrealtime();
+        const unsigned box = a.boxes[bi];
+        const int bx = box & 0xFF, by = (box >> 8) & 0xFFF, bz = box >> 20;
+        const int x = bx * 64 + (threadIdx.x & 63);
+        const int y = by * 4 + (threadIdx.x >> 6);
+        const bool in_vol = x < sx && y < sy;
+        const int zc0 = max(a.z0, bz * a.zchunk);
+        const int zc1 = min(a.z1, (bz + 1) * a.zchunk);
+        const f3 p0 = mk3(((float)x + 0.5f) * dimx / (float)sx, ((float)y + 0.5f) * dimy / (float)sy,
+                          (0.0f + 0.5f) * dimz / (float)sz);
+        f3 pos = xform(invTrack, p0);
+        f3 cameraX = xform(K, pos);
+        short2 *col = a.vol + (size_t)min(x, sx - 1) + (size_t)min(y, sy - 1) * sx;
+        {
+            // replay the additions of the steps below this chunk: same operations in the same order as a march
+            // from z = 0, two components per packed add
+            typedef float v2f __attribute__((ext_vector_type(2)));
+            v2f a0 = {pos.x, pos.y}, a1 = {pos.z, cameraX.x}, a2 = {cameraX.y, cameraX.z};
+            const v2f d0 = {delta.x, delta.y}, d1 = {delta.z, cameraDelta.x}, d2 = {cameraDelta.y, cameraDelta.z};
 #pragma unroll 8
-        for (int z = 0; z < zc0; ++z) {
-            a0 += d0;
-            a1 += d1;
-            a2 += d2;
-        }
-        pos = mk3(a0.x, a0.y, a1.x);
-        cameraX = mk3(a1.y, a2.x, a2.y);
-    }
-    // INTEGRATE_UNROLL z steps are advanced arithmetically, then their depth pixels and voxels are fetched
-    // together (the voxel read is issued as soon as the pixel test passes, before the depth value is
-    // known) and finally updated: one memory round trip per group instead of two per voxel.
-    for (int zb = zc0; zb < zc1; zb += INTEGRATE_UNROLL) {
-        f3 posk[INTEGRATE_UNROLL];
-        float camz[INTEGRATE_UNROLL];
-        unsigned pidx[INTEGRATE_UNROLL];
-        bool cand[INTEGRATE_UNROLL];
-#pragma unroll
-        for (int u = 0; u < INTEGRATE_UNROLL; ++u) {
-            const int z = zb + u;
-            posk[u] = pos;
-            camz[u] = cameraX.z;
-            bool c = z < zc1 && !(pos.z < 0.0001f);
-            // Cheap conservative rejection (one pixel of slack, far above the rounding of the exact test):
-            // a voxel that fails it cannot pass the exact in-image test below.
-            if (c && (cameraX.x < -1.5f * cameraX.z || cameraX.x > (wmax + 1.5f) * cameraX.z ||
-                      cameraX.y < -1.5f * cameraX.z || cameraX.y > (hmax + 1.5f) * cameraX.z))
-                c = false;
-            unsigned pi = 0;
-            if (c) {
-                const float r1 = refined_rcp(cameraX.z);
-                const float pxf = div_shared(cameraX.x, cameraX.z, r1) + 0.5f;
-                const float pyf = div_shared(cameraX.y, cameraX.z, r1) + 0.5f;
-                if (pxf < 0 || pxf > wmax || pyf < 0 || pyf > hmax) c = false;
-                else pi = (unsigned)pxf + (unsigned)pyf * (unsigned)w;
+            for (int z = 0; z < zc0; ++z) {
+                a0 += d0;
+                a1 += d1;
+                a2 += d2;
             }
-            cand[u] = c;
-            pidx[u] = pi;
-            pos = pos + delta;
-            cameraX = cameraX + cameraDelta;
+            pos = mk3(a0.x, a0.y, a1.x);
+            cameraX = mk3(a1.y, a2.x, a2.y);
         }
-        float dk[INTEGRATE_UNROLL];
-        short2 rawk[INTEGRATE_UNROLL];
+        // INTEGRATE_UNROLL z steps are advanced arithmetically, then their depth pixels and voxels are fetched
+        // together (the voxel read is issued as soon as the pixel test passes, before the depth value is
+        // known) and finally updated: one memory round trip per group instead of two per voxel.
+        for (int zb = zc0; zb < zc1; zb += INTEGRATE_UNROLL) {
+            f3 posk[INTEGRATE_UNROLL];
+            float camz[INTEGRATE_UNROLL];
+            unsigned pidx[INTEGRATE_UNROLL];
+            bool cand[INTEGRATE_UNROLL];
 #pragma unroll
-        for (int u = 0; u < INTEGRATE_UNROLL; ++u) {
-            dk[u] = 0.f;
-            rawk[u] = make_short2(0, 0);
-            if (cand[u]) {
-                dk[u] = depth[pidx[u]];
-                rawk[u] = col[(size_t)(zb + u - z0) * plane];
+            for (int u = 0; u < INTEGRATE_UNROLL; ++u) {
+                const int z = zb + u;
+                posk[u] = pos;
+                camz[u] = cameraX.z;
+                bool c = in_vol && z < zc1 && !(pos.z < 0.0001f);
+                // Cheap conservative rejection (one pixel of slack, far above the rounding of the exact test):
+                // a voxel that fails it cannot pass the exact in-image test below.
+                if (c && (cameraX.x < -1.5f * cameraX.z || cameraX.x > (wmax + 1.5f) * cameraX.z ||
+                          cameraX.y < -1.5f * cameraX.z || cameraX.y > (hmax + 1.5f) * cameraX.z))
+                    c = false;
+                unsigned pi = 0;
+                if (c) {
+                    const float r1 = refined_rcp(cameraX.z);
+                    const float pxf = div_shared(cameraX.x, cameraX.z, r1) + 0.5f;
+                    const float pyf = div_shared(cameraX.y, cameraX.z, r1) + 0.5f;
+                    if (pxf < 0 || pxf > wmax || pyf < 0 || pyf > hmax) c = false;
+                    else pi = (unsigned)pxf + (unsigned)pyf * (unsigned)w;
+                }
+                cand[u] = c;
+                pidx[u] = pi;
+                pos = pos + delta;
+                cameraX = cameraX + cameraDelta;
+            }
+            float dk[INTEGRATE_UNROLL];
+            short2 rawk[INTEGRATE_UNROLL];
+#pragma unroll
+            for (int u = 0; u < INTEGRATE_UNROLL; ++u) {
+                dk[u] = 0.f;
+                rawk[u] = make_short2(0, 0);
+                if (cand[u]) {
+                    dk[u] = depth[pidx[u]];
+                    rawk[u] = col[(size_t)(zb + u - a.z0) * plane];
+                }
+                if (a.dbg) dbg_cand += __popcll(__ballot(cand[u]));
+            }
+#pragma unroll
+            for (int u = 0; u < INTEGRATE_UNROLL; ++u) {
+                if (!cand[u] || dk[u] == 0) continue;
+                // diff = (d - z) * s with s = sqrt(1 + rx^2 + ry^2) >= 1, so
+                //   d - z <= -mu  implies  diff <= -mu        (voxel behind the surface: untouched)
+                //   d - z >=  mu  implies  min(1, diff / mu) == 1   (free space)
+                // and only the band in between needs s.
+                const float dz = dk[u] - camz[u];
+                if (dz <= -mu) continue;
+                float sdf = 1.f;
+                if (dz < mu) {
+                    const float r1 = refined_rcp(posk[u].z);
+                    const float rx = div_shared(posk[u].x, posk[u].z, r1), ry = div_shared(posk[u].y, posk[u].z, r1);
+                    const float diff = dz * sqrtf(1 + rx * rx + ry * ry);
+                    if (!(diff > -mu)) continue;
+                    sdf = fminf(1.f, diff / mu);
+                }
+                {
+                    float tsdf = (float)rawk[u].x * KFH_SHORT2FLOAT;
+                    float wgt = (float)rawk[u].y;
+                    tsdf = fmaxf(-1.f, fminf((wgt * tsdf + sdf) / (wgt + 1), 1.f));
+                    wgt = fminf(wgt + 1, maxweight);
+                    const short2 out = make_short2((short)(tsdf * KFH_FLOAT2SHORT), (short)wgt);
+                    // free space seen often enough stays at (1, maxweight): nothing to store then
+                    if (out.x != rawk[u].x || out.y != rawk[u].y) {
+                        col[(size_t)(zb + u - a.z0) * plane] = out;
+                        if (a.dbg) ++dbg_written;
+                    }
+                }
             }
         }
-#pragma unroll
-        for (int u = 0; u < INTEGRATE_UNROLL; ++u) {
-            if (!cand[u] || dk[u] == 0) continue;
-            // diff = (d - z) * s with s = sqrt(1 + rx^2 + ry^2) >= 1, so
-            //   d - z <= -mu  implies  diff <= -mu        (voxel behind the surface: untouched)
-            //   d - z >=  mu  implies  min(1, diff / mu) == 1   (free space)
-            // and only the band in between needs s.
-            const float dz = dk[u] - camz[u];
-            if (dz <= -mu) continue;
-            float sdf = 1.f;
-            if (dz < mu) {
-                const float r1 = refined_rcp(posk[u].z);
-                const float rx = div_shared(posk[u].x, posk[u].z, r1), ry = div_shared(posk[u].y, posk[u].z, r1);
-                const float diff = dz * sqrtf(1 + rx * rx + ry * ry);
-                if (!(diff > -mu)) continue;
-                sdf = fminf(1.f, diff / mu);
-            }
-            {
-                float tsdf = (float)rawk[u].x * KFH_SHORT2FLOAT;
-                float wgt = (float)rawk[u].y;
-                tsdf = fmaxf(-1.f, fminf((wgt * tsdf + sdf) / (wgt + 1), 1.f));
-                wgt = fminf(wgt + 1, maxweight);
-                col[(size_t)(zb + u - z0) * plane] = make_short2((short)(tsdf * KFH_FLOAT2SHORT), (short)wgt);
+        if (a.dbg) {
+            unsigned long long tot = dbg_written;
+            for (int m = 32; m >= 1; m >>= 1) tot += __shfl_xor(tot, m, 64);
+            if ((threadIdx.x & 63) == 0) {
+                unsigned long long *d = a.dbg + ((size_t)bi * 4 + (threadIdx.x >> 6)) * 4;
+                d[0] = dbg_t0;
+                d[1] = __builtin_amdgcn_s_memrealtime();
+                d[2] = dbg_cand;
+                d[3] = tot;
             }
         }
     }
 }
 
+static unsigned long long *g_integrate_debug = nullptr;   // diagnostics buffer, [box][4 wavefronts][4]
+void set_integrate_debug(unsigned long long *d_buffer) { g_integrate_debug = d_buffer; }
+
+size_t integrate_box_list_bytes(const int res[3], int z1) {
+    const int zchunk = z1 <= 512 ? 32 : 64;
+    return (size_t)((res[0] + 63) / 64) * ((res[1] + 3) / 4) * ((z1 + zchunk - 1) / zchunk) * sizeof(unsigned);
+}
+
 hipError_t launch_integrate(short2 *vol, const int res[3], const float dim[3], int z0, int z1,
                             const float *depth, int w, int h, const Mat4 *inv_track, Mat4 K, float mu,
-                            float maxweight, const int *gate, hipStream_t s) {
-    // Short z chunks: blocks whose box misses the camera frustum leave at once, the others replay the column
-    // prefix (a few packed adds per step) and then march only zchunk steps, so no wavefront runs long.
-    const int gx = (res[0] + 63) / 64, gy = (res[1] + 3) / 4;
-    const int zchunk = z1 <= 512 ? 32 : 64;
-    const int gz = (z1 + zchunk - 1) / zchunk;
-    const dim3 grid(gx, gy, gz);
-    hipLaunchKernelGGL(k_integrate, grid, dim3(256), 0, s, vol, res[0], res[1], res[2], dim[0], dim[1], dim[2],
-                       z0, z1, depth, w, h, inv_track, K, mu, maxweight, gate, zchunk);
+                            float maxweight, const int *gate, unsigned *boxes, unsigned *box_count, hipStream_t s) {
+    // Short z chunks: boxes that miss the camera frustum never reach the work launch, the others replay the
+    // column prefix (a few packed adds per step) and then march only zchunk steps, so no wavefront runs long.
+    IntegrateArgs a;
+    a.vol = vol;
+    a.sx = res[0]; a.sy = res[1]; a.sz = res[2];
+    a.dimx = dim[0]; a.dimy = dim[1]; a.dimz = dim[2];
+    a.z0 = z0; a.z1 = z1;
+    a.depth = depth; a.w = w; a.h = h;
+    a.inv_track = inv_track; a.K = K; a.mu = mu; a.maxweight = maxweight; a.gate = gate;
+    a.zchunk = z1 <= 512 ? 32 : 64;
+    a.gx = (res[0] + 63) / 64; a.gy = (res[1] + 3) / 4; a.gz = (z1 + a.zchunk - 1) / a.zchunk;
+    a.boxes = boxes; a.box_count = box_count;
+    a.dbg = g_integrate_debug;
+    if (a.gx > 256 || a.gy > 4096 || a.gz > 4096) return hipErrorInvalidValue;   // packed box id
+    const int nbox = a.gx * a.gy * a.gz;
+    hipLaunchKernelGGL(k_integrate_plan, dim3((nbox + 255) / 256), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(k_integrate, dim3(nbox < 2048 ? nbox : 2048), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 
@@ -1431,8 +1522,13 @@ hipError_t launch_fill_volume(short2 *vol, size_t nvox, hipStream_t s) {
 // and holds planes [zs0, zs1); the march is clipped to z in [zc0, zc1] metres (the whole volume, or the
 // owned slab in the sharded mode).
 // =====================================================================================================
-constexpr int RAY_BATCH = 4;      // steps one lane keeps in flight for its own ray
-constexpr int RAY_TAIL_MAX = 8;   // at most this many live rays: the wavefront marches them cooperatively
+constexpr int RAY_BATCH = 4;        // steps one lane keeps in flight for its own ray
+constexpr int RAY_MAX_ROUNDS = 10;  // first pass: at most 40 samples per ray (the median ray needs about 32)
+constexpr int RAY_FEW = 8;          // first pass ends for a wavefront with at most this many live rays
+constexpr int RAY_TAIL_BLOCKS = 1024;
+// smallest raw tsdf for which a trilinear sample is certainly >= 0.8:  26300 * 0.0000305194 = 0.8027, and
+// the interpolation of values >= m stays above m * (1 - 1e-6)
+constexpr int RAY_COARSE_SAFE = 26300;
 
 // value of `v` in lane `src`; src is the same for the whole wavefront
 __device__ inline float bcast_lane(float v, int src) {
@@ -1523,6 +1619,21 @@ struct VolDev {
         const Tap t = prep(pos);
         return combine(t, fetch(t));
     }
+    // Smallest of the eight raw tsdf values of a fetched sample (the low 16 bits of each voxel).  A march
+    // only needs the interpolated value when this minimum is small: with all eight values >= m > 0 the
+    // interpolation is a sum of non-negative products and stays >= m (1 - 1e-6).
+    __device__ static inline int min_tsdf(TapData d) {
+        asm("" : "+v"(d.r00), "+v"(d.r10), "+v"(d.r01), "+v"(d.r11));
+        typedef short s2 __attribute__((ext_vector_type(2)));
+        const unsigned a = __builtin_amdgcn_perm((unsigned)(d.r00 >> 32), (unsigned)d.r00, 0x05040100u);
+        const unsigned b = __builtin_amdgcn_perm((unsigned)(d.r10 >> 32), (unsigned)d.r10, 0x05040100u);
+        const unsigned c = __builtin_amdgcn_perm((unsigned)(d.r01 >> 32), (unsigned)d.r01, 0x05040100u);
+        const unsigned e = __builtin_amdgcn_perm((unsigned)(d.r11 >> 32), (unsigned)d.r11, 0x05040100u);
+        const s2 m = __builtin_elementwise_min(
+            __builtin_elementwise_min(__builtin_bit_cast(s2, a), __builtin_bit_cast(s2, b)),
+            __builtin_elementwise_min(__builtin_bit_cast(s2, c), __builtin_bit_cast(s2, e)));
+        return min((int)m.x, (int)m.y);
+    }
     __device__ inline f3 grad(f3 pos) const {
         const f3 sp = to_voxel(pos);
         const float flx = floorf(sp.x), fly = floorf(sp.y), flz = floorf(sp.z);
@@ -1563,22 +1674,12 @@ struct VolDev {
     }
 };
 
+// Ray through pixel (x, y) and its parameter range inside the (slab of the) volume and [near, far].
 template <bool POW2>
-__global__ __launch_bounds__(256, 5) void k_raycast(float4 *__restrict__ vertex, float4 *__restrict__ normal,
-                                                 float *__restrict__ ray_t, float4 *__restrict__ ref_tn, int w,
-                                                 int h, VolDev<POW2> vol,
-                                                 float zc0, float zc1, const Mat4 *__restrict__ view_p,
-                                                 float near_plane, float far_plane, float step,
-                                                 float largestep) {
-    // 16x16 pixel block, each wavefront an 8x8 tile
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int x = blockIdx.x * 16 + (wave & 1) * 8 + (lane & 7);
-    const int y = blockIdx.y * 16 + (wave >> 1) * 8 + (lane >> 3);
-    const bool inside = x < w && y < h;        // lanes outside the image stay as helpers of the tail phase
-    const Mat4 view = *view_p;
+__device__ inline void ray_setup(const VolDev<POW2> &vol, const Mat4 &view, int x, int y, float zc0, float zc1,
+                                 float near_plane, float far_plane, f3 &direction, float &tnear, float &tfar) {
     const f3 origin = mk3(view.m[3], view.m[7], view.m[11]);
-    const f3 direction = rotate(view, mk3((float)x, (float)y, 1.f));
-
+    direction = rotate(view, mk3((float)x, (float)y, 1.f));
     const f3 invR = mk3(1.0f / direction.x, 1.0f / direction.y, 1.0f / direction.z);
     const f3 box_lo = mk3(0.f, 0.f, zc0);
     const f3 box_hi = mk3(vol.dx, vol.dy, zc1);
@@ -1588,54 +1689,138 @@ __global__ __launch_bounds__(256, 5) void k_raycast(float4 *__restrict__ vertex,
     const f3 tmax = mk3(fmaxf(ttop.x, tbot.x), fmaxf(ttop.y, tbot.y), fmaxf(ttop.z, tbot.z));
     const float largest_tmin = fmaxf(fmaxf(tmin.x, tmin.y), fmaxf(tmin.x, tmin.z));
     const float smallest_tmax = fminf(fminf(tmax.x, tmax.y), fminf(tmax.x, tmax.z));
-    const float tnear = fmaxf(largest_tmin, near_plane);
-    const float tfar = fminf(smallest_tmax, far_plane);
+    tnear = fmaxf(largest_tmin, near_plane);
+    tfar = fminf(smallest_tmax, far_plane);
+}
 
-    // The reference loop is  for (; t < tfar; t += stepsize) { f_tt = interp(t); if (f_tt < 0) break;
-    // if (f_tt < 0.8) stepsize = step; f_t = f_tt; }.  Same samples and same decisions here, fetched in groups.
-    float t = tnear;
-    float stepsize = largestep;
-    float f_t = 0.f, f_tt = 0.f;
-    bool marching = false;
+// End of a ray: `hit` says the march stopped at a negative sample f_tt at parameter t, reached with step
+// `stepsize` from the sample at t_prev.  Interpolates the zero crossing, evaluates the normal and writes
+// the pixel of every output map.
+template <bool POW2>
+__device__ inline void finish_ray(const VolDev<POW2> &vol, f3 origin, f3 direction, bool hit, float t, float t_prev,
+                                  float stepsize, float f_tt, int o, float4 *__restrict__ vertex,
+                                  float4 *__restrict__ normal, float *__restrict__ ray_t,
+                                  float4 *__restrict__ ref_tn) {
+    float4 hitv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (hit) {
+        const float f_t = vol.interp(origin + direction * t_prev);     // value of the last sample before the crossing
+        const float th = t + stepsize * f_tt / (f_t - f_tt);
+        const f3 p = origin + direction * th;
+        hitv = make_float4(p.x, p.y, p.z, th);
+    }
+    float4 nrm = make_float4(KFH_INVALID, 0.f, 0.f, 0.f);
+    float4 vtx = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (hitv.w > 0.0f) {
+        vtx = make_float4(hitv.x, hitv.y, hitv.z, 0.f);
+        const f3 g = vol.grad(mk3(hitv.x, hitv.y, hitv.z));
+        if (length3(g) != 0) {
+            const f3 n = normalize3(g);
+            nrm = make_float4(n.x, n.y, n.z, 0.f);
+        }
+    }
+    vertex[o] = vtx;
+    normal[o] = nrm;
+    if (ray_t) ray_t[o] = hitv.w > 0.0f ? hitv.w : 0.f;
+    // packed model map for tracking: hit distance + normal (the vertex is origin + direction * t)
+    if (ref_tn) ref_tn[o] = make_float4(hitv.w > 0.0f ? hitv.w : 0.f, nrm.x, nrm.y, nrm.z);
+}
+
+// A ray the first pass left unfinished: next sample parameter, parameter of the last consumed sample, mode.
+struct RayTask {
+    int pixel;
+    float t, t_prev;
+    int fine;
+};
+
+// The reference loop per ray is
+//   for (; t < tfar; t += stepsize) { f_tt = interp(t); if (f_tt < 0) break; if (f_tt < 0.8) stepsize = step; f_t = f_tt; }
+// The same samples and decisions are taken here, but a sample is only interpolated when the smallest of its
+// eight raw values allows an event (below RAY_COARSE_SAFE with the coarse step, negative with the fine
+// step); f_t is evaluated once, at the end, from the remembered parameter of the previous sample.
+//
+// First pass: a wavefront is an 8x8 pixel tile and every lane marches its own ray, RAY_BATCH consecutive
+// samples fetched together (their positions only depend on the current step size; a step-size change
+// discards the rest of the batch).  A wavefront stops after RAY_MAX_ROUNDS batches, or when few of its
+// rays are still alive, and appends those rays to the task list of the second pass.
+template <bool POW2>
+__global__ __launch_bounds__(256, 5) void k_raycast_march(float4 *__restrict__ vertex, float4 *__restrict__ normal,
+                                                       float *__restrict__ ray_t, float4 *__restrict__ ref_tn,
+                                                       int w, int h, VolDev<POW2> vol, float zc0, float zc1,
+                                                       const Mat4 *__restrict__ view_p, float near_plane,
+                                                       float far_plane, float step, float largestep,
+                                                       RayTask *__restrict__ tasks, unsigned *task_count,
+                                                       int max_rounds, unsigned long long *dbg) {
+    // 16x16 pixel block, each wavefront an 8x8 tile
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // diagnostics (dbg != null): per wavefront {start, end} of the 100 MHz counter, batches, rays handed over
+    unsigned long long dbg_t0 = 0;
+    if (dbg) dbg_t0 = __builtin_amdgcn_s_memrealtime();
+    const int x = blockIdx.x * 16 + (wave & 1) * 8 + (lane & 7);
+    const int y = blockIdx.y * 16 + (wave >> 1) * 8 + (lane >> 3);
+    const bool inside = x < w && y < h;
+    const Mat4 view = *view_p;
+    const f3 origin = mk3(view.m[3], view.m[7], view.m[11]);
+    f3 direction;
+    float tnear, tfar;
+    ray_setup(vol, view, x, y, zc0, zc1, near_plane, far_plane, direction, tnear, tfar);
+
+    float t = tnear, t_prev = tnear, f_tt = 0.f;
+    bool fine = false, hit = false, marching = false;
     if (inside && tnear < tfar) {
-        f_t = vol.interp(origin + direction * t);
-        marching = f_t > 0;          // already inside the surface: nothing to render (t < tfar holds here)
+        const auto tap = vol.prep(origin + direction * t);
+        const auto raw = vol.fetch(tap);
+        // already inside the surface: nothing to render
+        marching = VolDev<POW2>::min_tsdf(raw) > 0 ? true : vol.combine(tap, raw) > 0;
     }
 
-    // Phase 1, while many rays of the wavefront are alive: every lane fetches RAY_BATCH consecutive steps of
-    // its own ray together (their positions only depend on the current step size) and consumes them in
-    // order; a step-size change discards the rest of the batch.
+    int rounds = 0;
     while (true) {
         const unsigned long long alive = __ballot(marching);
-        if (alive == 0 || __popcll(alive) <= RAY_TAIL_MAX) break;
+        if (alive == 0 || __popcll(alive) <= RAY_FEW || rounds == max_rounds) break;
+        ++rounds;
         if (marching) {
+            const float stepsize = fine ? step : largestep;
             float tk[RAY_BATCH], fk[RAY_BATCH];
+            f3 pos[RAY_BATCH];
             tk[0] = t;
 #pragma unroll
             for (int k = 1; k < RAY_BATCH; ++k) tk[k] = tk[k - 1] + stepsize;
-            typename VolDev<POW2>::Tap taps[RAY_BATCH];
             typename VolDev<POW2>::TapData raw[RAY_BATCH];
 #pragma unroll
             for (int k = 0; k < RAY_BATCH; ++k) {
                 const float ts = tk[k] < tfar ? tk[k] : t;      // never sample past the far bound
-                taps[k] = vol.prep(origin + direction * ts);
+                pos[k] = origin + direction * ts;
             }
 #pragma unroll
-            for (int k = 0; k < RAY_BATCH; ++k) raw[k] = vol.fetch(taps[k]);
+            for (int k = 0; k < RAY_BATCH; ++k) raw[k] = vol.fetch(vol.prep(pos[k]));
+            bool need[RAY_BATCH], any_need = false;
 #pragma unroll
-            for (int k = 0; k < RAY_BATCH; ++k) fk[k] = vol.combine(taps[k], raw[k]);
+            for (int k = 0; k < RAY_BATCH; ++k) {
+                const int mn = VolDev<POW2>::min_tsdf(raw[k]);
+                need[k] = fine ? mn < 0 : mn < RAY_COARSE_SAFE;
+                any_need = any_need || need[k];
+                fk[k] = 1.0f;                                   // stands for "no event possible"
+            }
+            if (any_need) {
+#pragma unroll
+                for (int k = 0; k < RAY_BATCH; ++k) {
+                    if (need[k]) {
+                        f3 p = pos[k];
+                        asm volatile("" : "+v"(p.x), "+v"(p.y), "+v"(p.z));   // recompute the fractions here
+                        fk[k] = vol.combine(vol.prep(p), raw[k]);
+                    }
+                }
+            }
             bool restart = false;
 #pragma unroll
             for (int k = 0; k < RAY_BATCH; ++k) {
                 if (!marching || restart) continue;
-                if (!(tk[k] < tfar)) { t = tk[k]; marching = false; continue; }
-                f_tt = fk[k];
-                t = tk[k];
-                if (f_tt < 0) { marching = false; continue; }
-                f_t = f_tt;
-                if (f_tt < 0.8f && stepsize != step) {
-                    stepsize = step;
-                    t = tk[k] + stepsize;
+                if (!(tk[k] < tfar)) { marching = false; continue; }           // left the volume: no hit
+                if (fk[k] < 0) { t = tk[k]; f_tt = fk[k]; hit = true; marching = false; continue; }
+                t_prev = tk[k];
+                if (fk[k] < 0.8f && !fine) {
+                    fine = true;
+                    t = tk[k] + step;
                     restart = true;
                 }
             }
@@ -1643,90 +1828,123 @@ __global__ __launch_bounds__(256, 5) void k_raycast(float4 *__restrict__ vertex,
         }
     }
 
-    // Phase 2, the tail: a few long rays (grazing a surface with the fine step) would otherwise keep the
-    // wavefront alive for dozens of dependent round trips.  The wavefront takes them one at a time and lets
-    // lane k evaluate step k of that ray, 64 steps per round trip; the first lane (in step order) that
-    // meets a loop exit or a step-size change decides, exactly as the sequential loop would.
-    unsigned long long pending = __ballot(marching);
-    while (pending) {
-        const int src = __ffsll((long long)pending) - 1;
-        pending &= pending - 1;
-        const f3 bdir = mk3(bcast_lane(direction.x, src), bcast_lane(direction.y, src), bcast_lane(direction.z, src));
-        const float btfar = bcast_lane(tfar, src);
-        float bt = bcast_lane(t, src), bstep = bcast_lane(stepsize, src), bft = bcast_lane(f_t, src);
-        float r_ftt = 0.f;
-        bool go = true;
-        while (go) {                                            // wave-uniform
-            float tk = bt;                                      // lane k: bt advanced k times, one add at a time
-#pragma unroll 9
-            for (int i = 0; i < 63; ++i) tk = lane > i ? tk + bstep : tk;
-            const bool valid = tk < btfar;
-            const float f = vol.interp(origin + bdir * (valid ? tk : bt));
-            const bool coarse = bstep != step;
-            const unsigned long long m_end = __ballot(!valid);
-            const unsigned long long m_neg = __ballot(valid && f < 0.f);
-            const unsigned long long m_near = coarse ? __ballot(valid && !(f < 0.f) && f < 0.8f) : 0ull;
-            const unsigned long long events = m_end | m_neg | m_near;
-            if (events == 0) {                                  // all 64 steps consumed, none decisive
-                bft = bcast_lane(f, 63);
-                bt = bcast_lane(tk, 63) + bstep;
-                continue;
-            }
-            const int first = __ffsll((long long)events) - 1;
-            const float f_first = bcast_lane(f, first), t_first = bcast_lane(tk, first);
-            if (first > 0) bft = bcast_lane(f, first - 1);      // value of the step before the event
-            if ((m_end >> first) & 1ull) {                      // ran past the far bound: no hit
-                bt = t_first;
-                r_ftt = 0.f;
-                go = false;
-            } else if ((m_neg >> first) & 1ull) {               // zero crossing
-                bt = t_first;
-                r_ftt = f_first;
-                go = false;
-            } else {                                            // first sample below 0.8: switch to the fine step
-                bft = f_first;
-                bstep = step;
-                bt = t_first + step;
-            }
-        }
-        if (lane == src) {
-            t = bt;
-            stepsize = bstep;
-            f_t = bft;
-            f_tt = r_ftt;
-            marching = false;
+    // rays still marching go to the second pass
+    const unsigned long long left = __ballot(marching);
+    if (left) {
+        const int first = __ffsll((long long)left) - 1;
+        unsigned base = 0;
+        if (lane == first) base = atomicAdd(task_count, (unsigned)__popcll(left));
+        base = __builtin_amdgcn_readlane(base, first);
+        if (marching) {
+            RayTask e;
+            e.pixel = x + y * w;
+            e.t = t;
+            e.t_prev = t_prev;
+            e.fine = fine ? 1 : 0;
+            tasks[base + __popcll(left & ((1ull << lane) - 1ull))] = e;
         }
     }
-
-    float4 hit = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (f_tt < 0) {
-        t = t + stepsize * f_tt / (f_t - f_tt);
-        const f3 p = origin + direction * t;
-        hit = make_float4(p.x, p.y, p.z, t);
+    if (inside && !marching)
+        finish_ray(vol, origin, direction, hit, t, t_prev, fine ? step : largestep, f_tt, x + y * w, vertex, normal,
+                   ray_t, ref_tn);
+    if (dbg && lane == 0) {
+        unsigned long long *d = dbg + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave) * 4;
+        d[0] = dbg_t0;
+        d[1] = __builtin_amdgcn_s_memrealtime();
+        d[2] = rounds;
+        d[3] = __popcll(left);
     }
-    if (!inside) return;
-    const int o = x + y * w;
-    float4 nrm = make_float4(KFH_INVALID, 0.f, 0.f, 0.f);
-    if (hit.w > 0.0f) {
-        const f3 g = vol.grad(mk3(hit.x, hit.y, hit.z));
-        if (length3(g) != 0) {
-            const f3 n = normalize3(g);
-            nrm = make_float4(n.x, n.y, n.z, 0.f);
-        }
-    }
-    vertex[o] = make_float4(hit.x, hit.y, hit.z, 0.f);
-    normal[o] = nrm;
-    // packed model map for tracking: hit distance + normal (the vertex is origin + direction * t)
-    if (ref_tn) ref_tn[o] = make_float4(hit.w, nrm.x, nrm.y, nrm.z);
-    if (ray_t) ray_t[o] = hit.w;
 }
+
+// Second pass: RAY_TAIL_LANES lanes share one unfinished ray; lane k of the group evaluates step k of the
+// next RAY_TAIL_LANES steps (parameters by repeated addition, exactly as the sequential loop produces
+// them), and the first lane in step order that meets a loop exit or a step-size change decides.  Long
+// rays (grazing a surface with the fine step) thus take a sixteenth of the dependent round trips, and
+// the task list spreads them over the whole device instead of the few tiles they come from.
+template <bool POW2, int RAY_TAIL_LANES>
+__global__ __launch_bounds__(256) void k_raycast_tail(float4 *__restrict__ vertex, float4 *__restrict__ normal,
+                                                      float *__restrict__ ray_t, float4 *__restrict__ ref_tn, int w,
+                                                      int h, VolDev<POW2> vol, float zc0, float zc1,
+                                                      const Mat4 *__restrict__ view_p, float near_plane,
+                                                      float far_plane, float step, float largestep,
+                                                      const RayTask *__restrict__ tasks,
+                                                      const unsigned *__restrict__ task_count) {
+    constexpr int GROUPS = 64 / RAY_TAIL_LANES;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int grp = lane / RAY_TAIL_LANES, sub = lane % RAY_TAIL_LANES;
+    const int grp_lane0 = grp * RAY_TAIL_LANES;
+    const unsigned n = *task_count;
+    const unsigned stride = gridDim.x * 4 * GROUPS;
+    const Mat4 view = *view_p;
+    const f3 origin = mk3(view.m[3], view.m[7], view.m[11]);
+    for (unsigned base = (blockIdx.x * 4 + wave) * GROUPS; base < n; base += stride) {      // wave-uniform
+        const unsigned gi = base + grp;
+        const bool have = gi < n;
+        RayTask e;
+        e.pixel = 0; e.t = 0.f; e.t_prev = 0.f; e.fine = 1;
+        if (have) e = tasks[gi];
+        const int py = e.pixel / w, px = e.pixel - py * w;
+        f3 direction;
+        float tnear, tfar;
+        ray_setup(vol, view, px, py, zc0, zc1, near_plane, far_plane, direction, tnear, tfar);
+        float bt = e.t, t_prev = e.t_prev, f_hit = 0.f;
+        bool fine = e.fine != 0, go = have, hit = false;
+        while (__ballot(go)) {                                                // wave-uniform
+            const float stepsize = fine ? step : largestep;
+            float tk = bt;                                                    // bt advanced `sub` times
+#pragma unroll
+            for (int i = 0; i < RAY_TAIL_LANES - 1; ++i) tk = sub > i ? tk + stepsize : tk;
+            const bool valid = tk < tfar;
+            const auto tap = vol.prep(origin + direction * (valid ? tk : bt));
+            const auto raw = vol.fetch(tap);
+            const int mn = VolDev<POW2>::min_tsdf(raw);
+            const bool need = go && valid && (fine ? mn < 0 : mn < RAY_COARSE_SAFE);
+            float f = 1.0f;
+            if (need) f = vol.combine(tap, raw);
+            constexpr unsigned long long GMASK = RAY_TAIL_LANES == 64 ? ~0ull : ((1ull << (RAY_TAIL_LANES & 63)) - 1ull);
+            const unsigned long long m_end = (__ballot(go && !valid) >> grp_lane0) & GMASK;
+            const unsigned long long m_neg = (__ballot(go && valid && f < 0.f) >> grp_lane0) & GMASK;
+            const unsigned long long m_near =
+                (__ballot(go && valid && !fine && !(f < 0.f) && f < 0.8f) >> grp_lane0) & GMASK;
+            const unsigned long long events = m_end | m_neg | m_near;
+            const int first = events ? __ffsll((long long)events) - 1 : RAY_TAIL_LANES - 1;
+            // all cross-lane reads are taken by every lane, outside divergent control flow
+            const float t_first = __shfl(tk, grp_lane0 + first, 64);
+            const float f_first = __shfl(f, grp_lane0 + first, 64);
+            const float t_before = __shfl(tk, grp_lane0 + max(first - 1, 0), 64);
+            if (go) {
+                if (events == 0) {                          // all steps of the group consumed, none decisive
+                    t_prev = t_first;                       // first == last lane here
+                    bt = t_first + stepsize;
+                } else if ((m_end >> first) & 1ull) {       // ran past the far bound: no hit
+                    go = false;
+                } else if ((m_neg >> first) & 1ull) {       // zero crossing
+                    hit = true;
+                    bt = t_first;
+                    f_hit = f_first;
+                    if (first > 0) t_prev = t_before;
+                    go = false;
+                } else {                                    // first sample below 0.8: switch to the fine step
+                    fine = true;
+                    t_prev = t_first;
+                    bt = t_first + step;
+                }
+            }
+        }
+        if (have && sub == 0)
+            finish_ray(vol, origin, direction, hit, bt, t_prev, fine ? step : largestep, f_hit, e.pixel, vertex, normal,
+                       ray_t, ref_tn);
+    }
+}
+
+static unsigned long long *g_raycast_debug = nullptr;   // diagnostics buffer, [blocks][4 waves][4]
+void set_raycast_debug(unsigned long long *d_buffer) { g_raycast_debug = d_buffer; }
 
 template <bool POW2>
 static hipError_t launch_raycast_t(float4 *vertex, float4 *normal, float *ray_t, float4 *ref_tn, int w, int h,
-                                   const short2 *vol,
-                                   const int res[3], const float dim[3], int z0, int z1, const Mat4 *view,
-                                   float near_plane, float far_plane, float step, float largestep,
-                                   hipStream_t s) {
+                                   const short2 *vol, const int res[3], const float dim[3], int z0, int z1,
+                                   const Mat4 *view, float near_plane, float far_plane, float step, float largestep,
+                                   void *tasks, unsigned *task_count, hipStream_t s) {
     VolDev<POW2> v;
     v.data = vol;
     v.sx = res[0]; v.sy = res[1]; v.sz = res[2];
@@ -1745,15 +1963,31 @@ static hipError_t launch_raycast_t(float4 *vertex, float4 *normal, float *ray_t,
         zc1 = (float)(z1 < res[2] ? z1 + 1 : z1) * (dim[2] / (float)res[2]);
     }
     const dim3 grid((w + 15) / 16, (h + 15) / 16);
-    hipLaunchKernelGGL(k_raycast<POW2>, grid, dim3(256), 0, s, vertex, normal, ray_t, ref_tn, w, h, v, zc0, zc1, view,
-                       near_plane, far_plane, step, largestep);
+    // tuning knobs for experiments (defaults: RAY_MAX_ROUNDS, 32 lanes per unfinished ray)
+    static const int max_rounds = std::getenv("KFH_RAY_ROUNDS") ? std::atoi(std::getenv("KFH_RAY_ROUNDS")) : RAY_MAX_ROUNDS;
+    static const int tail_lanes = std::getenv("KFH_RAY_TAIL_LANES") ? std::atoi(std::getenv("KFH_RAY_TAIL_LANES")) : 32;
+    hipLaunchKernelGGL(k_raycast_march<POW2>, grid, dim3(256), 0, s, vertex, normal, ray_t, ref_tn, w, h, v, zc0, zc1,
+                       view, near_plane, far_plane, step, largestep, static_cast<RayTask *>(tasks), task_count,
+                       max_rounds, g_raycast_debug);
+    const RayTask *ct = static_cast<const RayTask *>(tasks);
+    if (tail_lanes == 64)
+        hipLaunchKernelGGL((k_raycast_tail<POW2, 64>), dim3(RAY_TAIL_BLOCKS * 2), dim3(256), 0, s, vertex, normal, ray_t,
+                           ref_tn, w, h, v, zc0, zc1, view, near_plane, far_plane, step, largestep, ct, task_count);
+    else if (tail_lanes == 32)
+        hipLaunchKernelGGL((k_raycast_tail<POW2, 32>), dim3(RAY_TAIL_BLOCKS), dim3(256), 0, s, vertex, normal, ray_t,
+                           ref_tn, w, h, v, zc0, zc1, view, near_plane, far_plane, step, largestep, ct, task_count);
+    else
+        hipLaunchKernelGGL((k_raycast_tail<POW2, 16>), dim3(RAY_TAIL_BLOCKS), dim3(256), 0, s, vertex, normal, ray_t,
+                           ref_tn, w, h, v, zc0, zc1, view, near_plane, far_plane, step, largestep, ct, task_count);
     return hipGetLastError();
 }
 
+size_t raycast_task_bytes(int w, int h) { return (size_t)w * h * sizeof(RayTask); }
+
 hipError_t launch_raycast(float4 *vertex, float4 *normal, float *ray_t, float4 *ref_tn, int w, int h,
-                          const short2 *vol,
-                          const int res[3], const float dim[3], int z0, int z1, const Mat4 *view,
-                          float near_plane, float far_plane, float step, float largestep, hipStream_t s) {
+                          const short2 *vol, const int res[3], const float dim[3], int z0, int z1, const Mat4 *view,
+                          float near_plane, float far_plane, float step, float largestep, void *tasks,
+                          unsigned *task_count, hipStream_t s) {
     bool pow2 = true;
     for (int i = 0; i < 3; ++i) {
         int e = 0;
@@ -1762,9 +1996,9 @@ hipError_t launch_raycast(float4 *vertex, float4 *normal, float *ray_t, float4 *
         if (!dim_pow2 || !res_pow2 || res[i] < 2) pow2 = false;
     }
     return pow2 ? launch_raycast_t<true>(vertex, normal, ray_t, ref_tn, w, h, vol, res, dim, z0, z1, view, near_plane,
-                                         far_plane, step, largestep, s)
+                                         far_plane, step, largestep, tasks, task_count, s)
                 : launch_raycast_t<false>(vertex, normal, ray_t, ref_tn, w, h, vol, res, dim, z0, z1, view, near_plane,
-                                          far_plane, step, largestep, s);
+                                          far_plane, step, largestep, tasks, task_count, s);
 }
 
 // Per pixel, keep the slab candidate with the smallest positive hit distance.
