@@ -241,7 +241,9 @@ int kfh_create(const kfh_config *cfg, kfh_context **out) {
         int rows = 1;
         for (int l = 0; l < 3; ++l) {
             const int wl = c->w >> l, hl = c->h >> l;
-            const int nb = track_blocks(wl, hl, track_ppt(wl, hl, c->compute_units));
+            int pw, ppt;
+            track_shape(wl, hl, c->compute_units, &pw, &ppt);
+            const int nb = track_blocks(wl, hl, pw, ppt);
             if (nb > rows) rows = nb;
         }
         c->partials_stride = (size_t)rows * 32;
@@ -301,8 +303,10 @@ int kfh_set_depth_device(kfh_context *c, const uint16_t *d_depth) {
 int kfh_preprocess(kfh_context *c) {
     KFH_REQUIRE(c != nullptr, "context is NULL");
     if (c->timing == 1) KFH_HIP(hipEventRecord(c->ev[c->frame % KFH_TIMING_RING][0], c->stream));
+    // the depth pyramid of tracking (halfSampleRobustImageKernel twice) is produced by the same launch
     KFH_HIP(launch_preprocess(c->d_float_depth, c->d_scaled[0], c->w, c->h, c->d_depth_cur, true,
-                              c->cfg.input_width, c->cfg.compute_size_ratio, c->cfg.depth_divisor, c->stream));
+                              c->cfg.input_width, c->cfg.compute_size_ratio, c->cfg.depth_divisor, c->d_scaled[1],
+                              c->d_scaled[2], E_DELTA * 3, c->stream));
     c->depth_version++;
     if (c->timing == 1) KFH_HIP(hipEventRecord(c->ev[c->frame % KFH_TIMING_RING][1], c->stream));
     return KFH_OK;
@@ -315,10 +319,6 @@ int kfh_track(kfh_context *c) {
     if (c->frame % c->cfg.tracking_rate != 0 || total_iterations == 0) {
         KFH_HIP(launch_track_skip(finish_args(c, 0, 0), c->stream));
     } else {
-        c->depth_version++;
-        for (int l = 1; l < 3; ++l)
-            KFH_HIP(launch_half_sample(c->d_scaled[l], c->d_scaled[l - 1], c->w >> (l - 1), c->h >> (l - 1),
-                                       E_DELTA * 3, c->stream));
         // depth2vertex / vertex2normal are evaluated inside the iteration kernel from the depth pyramid;
         // the vertex / normal maps themselves are only materialised when a caller asks for them
         IcpIterArgs a;
@@ -339,7 +339,7 @@ int kfh_track(kfh_context *c) {
             for (int i = 0; i < 4; ++i) a.k[i] = c->k[i] / (float)(1 << level);
             a.iw = c->w >> level;
             a.ih = c->h >> level;
-            a.ppt = track_ppt(a.iw, a.ih, c->compute_units);
+            track_shape(a.iw, a.ih, c->compute_units, &a.pw, &a.ppt);
             for (int i = 0; i < c->cfg.pyramid[level]; ++i, ++seq) {
                 a.seq = seq;
                 a.last_iter = (i == c->cfg.pyramid[level] - 1) ? 1 : 0;
@@ -347,7 +347,7 @@ int kfh_track(kfh_context *c) {
                 a.partials_out = c->d_partials + (size_t)((seq + 1) & 1) * c->partials_stride;
                 a.pending_rows = rows;
                 KFH_HIP(launch_icp_iteration(a, c->stream));
-                rows = track_blocks(a.iw, a.ih, a.ppt);
+                rows = track_blocks(a.iw, a.ih, a.pw, a.ppt);
             }
         }
         KFH_HIP(launch_icp_finish(finish_args(c, seq, rows), c->stream));
@@ -631,14 +631,15 @@ int kfh_k_preprocess(float *d_raw, float *d_filtered, int ow, int oh, const uint
     KFH_REQUIRE(ow > 0 && oh > 0 && iw >= ow && ih >= oh, "bad sizes");
     KFH_REQUIRE(iw % ow == 0 && ih % oh == 0 && iw / ow == ih / oh, "input size must be an integer multiple of the output size");
     KFH_REQUIRE(depth_divisor > 0.f, "depth_divisor must be positive");
-    KFH_HIP(launch_preprocess(d_raw, d_filtered, ow, oh, d_in, true, iw, iw / ow, depth_divisor,
+    KFH_HIP(launch_preprocess(d_raw, d_filtered, ow, oh, d_in, true, iw, iw / ow, depth_divisor, nullptr, nullptr, 0.f,
                               static_cast<hipStream_t>(stream)));
     return KFH_OK;
 }
 
 int kfh_k_bilateral(float *d_out, const float *d_in, int w, int h, void *stream) {
     KFH_REQUIRE(d_out && d_in && w > 0 && h > 0, "bad argument");
-    KFH_HIP(launch_preprocess(nullptr, d_out, w, h, d_in, false, w, 1, 1.0f, static_cast<hipStream_t>(stream)));
+    KFH_HIP(launch_preprocess(nullptr, d_out, w, h, d_in, false, w, 1, 1.0f, nullptr, nullptr, 0.f,
+                              static_cast<hipStream_t>(stream)));
     return KFH_OK;
 }
 
@@ -666,7 +667,9 @@ int kfh_k_track_reduce(float *d_sums, kfh_track_data *d_track, int track_stride,
     KFH_REQUIRE(k[0] != 0.f && k[1] != 0.f, "focal lengths must be non-zero");
     KFH_REQUIRE(!d_track || track_stride >= iw, "track_stride must be >= iw");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const int nb = track_blocks(iw, ih, track_ppt(iw, ih, 256));
+    int tpw, tppt;
+    track_shape(iw, ih, 256, &tpw, &tppt);
+    const int nb = track_blocks(iw, ih, tpw, tppt);
     char *scratch = nullptr;   // [control block | partial rows]
     const size_t ctrl_bytes = (sizeof(Ctrl) + 255) & ~(size_t)255;
     KFH_HIP(hipMalloc(reinterpret_cast<void **>(&scratch), ctrl_bytes + (size_t)nb * 32 * sizeof(float)));

@@ -41,26 +41,33 @@ struct Ctrl {
 };
 
 // Tracking block: wavefront 0 finalises the previous iteration (row sum, 6x6 solve, pose update) while
-// wavefronts 1..4 prepare and then evaluate the pixels of a 64 x (4 * PPT) tile, PPT rows per thread.
-constexpr int KFH_TRACK_PIXEL_WAVES = 4;
-constexpr int KFH_TRACK_THREADS = 64 * (1 + KFH_TRACK_PIXEL_WAVES);
+// PW pixel wavefronts (4 or 8) prepare and then evaluate the pixels of a 64 x (PW * PPT) tile, PPT rows per
+// thread.  A SIMD issues one vector instruction every 4 cycles for a lone wavefront but every 2 cycles with
+// two, so 8 pixel wavefronts (two per SIMD) evaluate twice the tile in the same time.
 constexpr int KFH_TRACK_TILE_W = 64;
+constexpr int KFH_TRACK_MAX_THREADS = 64 * (1 + 8);
 constexpr int KFH_SUM_THREADS = 256;      // block size of the stand-alone row sum / finish kernels
 constexpr int KFH_STATUS_RING = 4096;
 // diagnostic time stamps: [launch][block][slot]
-constexpr int KFH_STAMP_LAUNCHES = 64, KFH_STAMP_BLOCKS = 320, KFH_STAMP_SLOTS = 12;
+constexpr int KFH_STAMP_LAUNCHES = 64, KFH_STAMP_BLOCKS = 320, KFH_STAMP_SLOTS = 14;
 
-inline int track_blocks(int w, int h, int ppt) {
-    const int tile_h = KFH_TRACK_PIXEL_WAVES * ppt;
+inline int track_blocks(int w, int h, int pw, int ppt) {
+    const int tile_h = pw * ppt;
     return ((w + KFH_TRACK_TILE_W - 1) / KFH_TRACK_TILE_W) * ((h + tile_h - 1) / tile_h);
 }
-// Rows per thread for an image: the fewest (of the instantiated 1, 2, 3, 5, 8) whose grid still fits on
-// `max_blocks` compute units at one block each, so that no unit gets a second tile.
-inline int track_ppt(int w, int h, int max_blocks) {
-    const int choices[] = {1, 2, 3, 5, 8};
-    for (int c : choices)
-        if (track_blocks(w, h, c) <= max_blocks) return c;
-    return 8;
+// Tile shape for an image: the instantiated (pixel wavefronts, rows per thread) pair with the fewest rows per
+// thread whose grid still fits on `max_blocks` compute units at one block each (no unit gets a second tile);
+// ties go to the smaller block.
+inline void track_shape(int w, int h, int max_blocks, int *pw, int *ppt) {
+    static const int shapes[][2] = {{4, 1}, {8, 1}, {4, 2}, {8, 2}, {4, 3}, {8, 3}, {4, 5}, {8, 5}, {4, 8}, {8, 8}};
+    for (const auto &sh : shapes)
+        if (track_blocks(w, h, sh[0], sh[1]) <= max_blocks) {
+            *pw = sh[0];
+            *ppt = sh[1];
+            return;
+        }
+    *pw = 8;
+    *ppt = 8;
 }
 
 struct IcpIterArgs {
@@ -81,7 +88,7 @@ struct IcpIterArgs {
     int rw, rh;
     float dist_threshold, normal_threshold, icp_threshold;
     float dist2_max;            // set by the launcher: largest d2 with sqrtf(d2) <= dist_threshold
-    int ppt;                    // rows per thread (tile height / 4); 0 = chosen by the launcher
+    int pw, ppt;                // pixel wavefronts per block and rows per thread; 0 = chosen by the launcher
     int max_blocks;             // compute units of the device (for that choice)
     kfh_track_data *track_out;  // per-pixel TrackData for parity tests, may be null
     int track_stride;
@@ -103,8 +110,10 @@ struct FinishArgs {
     kfh_frame_status *status_ring;
 };
 
+// level1 / level2 (both or neither): also write the two robust half-samplings of the filtered image
 hipError_t launch_preprocess(float *raw, float *filtered, int ow, int oh, const void *in, bool in_is_u16,
-                             int iw, int ratio, float divisor, hipStream_t s);
+                             int iw, int ratio, float divisor, float *level1, float *level2, float pyramid_e_d,
+                             hipStream_t s);
 hipError_t launch_half_sample(float *out, const float *in, int iw, int ih, float e_d, hipStream_t s);
 hipError_t launch_vertex_normal(float4 *vertex, float4 *normal, const float *depth, int w, int h, float fx,
                                 float fy, float cx, float cy, hipStream_t s);

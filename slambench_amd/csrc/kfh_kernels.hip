@@ -27,11 +27,29 @@ struct BilateralConst {
     float e_d_squared_2;   // 2 * e_d^2, e_d = 0.1
 };
 
-template <bool IN_U16>
+// halfSampleRobustImageKernel (r = 1) on a 2x2 block whose top-left pixel is `center`
+__device__ inline float half_sample_2x2(float tl, float tr, float bl, float br, float e_d) {
+    const float center = tl;
+    float sum = 0.0f, t = 0.0f;
+    // upstream order: i (row) outer, j (column) inner
+    if (fabsf(tl - center) < e_d) { sum += 1.0f; t += tl; }
+    if (fabsf(tr - center) < e_d) { sum += 1.0f; t += tr; }
+    if (fabsf(bl - center) < e_d) { sum += 1.0f; t += bl; }
+    if (fabsf(br - center) < e_d) { sum += 1.0f; t += br; }
+    return t / sum;
+}
+
+// With PYRAMID the block also half-samples its filtered 32x8 tile twice (16x4, then 8x2 pixels: the 2x2 blocks
+// of the robust half-sampling never straddle a tile), so the depth pyramid costs no further launches.
+template <bool IN_U16, bool PYRAMID>
 __global__ __launch_bounds__(256) void k_preprocess(float *__restrict__ raw, float *__restrict__ filtered,
                                                     int ow, int oh, const void *__restrict__ in, int iw,
-                                                    int ratio, float divisor, BilateralConst bc) {
+                                                    int ratio, float divisor, BilateralConst bc,
+                                                    float *__restrict__ level1, float *__restrict__ level2,
+                                                    float pyramid_e_d) {
     __shared__ float tile[PRE_LH][PRE_LW];
+    __shared__ float f0[PRE_TY][PRE_TX];
+    __shared__ float f1[PRE_TY / 2][PRE_TX / 2];
     const int tid = threadIdx.x;
     const int bx = blockIdx.x * PRE_TX, by = blockIdx.y * PRE_TY;
     for (int idx = tid; idx < PRE_LW * PRE_LH; idx += 256) {
@@ -50,26 +68,49 @@ __global__ __launch_bounds__(256) void k_preprocess(float *__restrict__ raw, flo
     __syncthreads();
     const int tx = tid & (PRE_TX - 1), ty = tid >> 5;
     const int x = bx + tx, y = by + ty;
-    if (x >= ow || y >= oh) return;
+    const bool inside = x < ow && y < oh;
     const float center = tile[ty + PRE_R][tx + PRE_R];
-    if (raw) raw[x + y * ow] = center;
-    if (!filtered) return;
-    if (center == 0) { filtered[x + y * ow] = 0; return; }
-    float sum = 0.0f, t = 0.0f;
+    if (inside && raw) raw[x + y * ow] = center;
+    float result = 0.f;
+    if (filtered && center != 0) {
+        float sum = 0.0f, t = 0.0f;
 #pragma unroll
-    for (int i = -PRE_R; i <= PRE_R; ++i) {
+        for (int i = -PRE_R; i <= PRE_R; ++i) {
 #pragma unroll
-        for (int j = -PRE_R; j <= PRE_R; ++j) {
-            const float cur = tile[ty + PRE_R + j][tx + PRE_R + i];
-            if (cur > 0) {
-                const float mod = (cur - center) * (cur - center);
-                const float factor = bc.g[i + PRE_R] * bc.g[j + PRE_R] * expf(-mod / bc.e_d_squared_2);
-                t += factor * cur;
-                sum += factor;
+            for (int j = -PRE_R; j <= PRE_R; ++j) {
+                const float cur = tile[ty + PRE_R + j][tx + PRE_R + i];
+                if (cur > 0) {
+                    const float mod = (cur - center) * (cur - center);
+                    const float factor = bc.g[i + PRE_R] * bc.g[j + PRE_R] * expf(-mod / bc.e_d_squared_2);
+                    t += factor * cur;
+                    sum += factor;
+                }
             }
         }
+        result = t / sum;
     }
-    filtered[x + y * ow] = t / sum;
+    if (inside && filtered) filtered[x + y * ow] = result;
+    if (!PYRAMID) return;
+    // the image sizes are multiples of 4, so a tile is either fully inside the image or cut at a multiple of 4
+    f0[ty][tx] = result;
+    __syncthreads();
+    const int ow1 = ow / 2, oh1 = oh / 2, ow2 = ow / 4, oh2 = oh / 4;
+    if (tid < (PRE_TX / 2) * (PRE_TY / 2)) {
+        const int hx = tid % (PRE_TX / 2), hy = tid / (PRE_TX / 2);
+        const float v = half_sample_2x2(f0[2 * hy][2 * hx], f0[2 * hy][2 * hx + 1], f0[2 * hy + 1][2 * hx],
+                                        f0[2 * hy + 1][2 * hx + 1], pyramid_e_d);
+        f1[hy][hx] = v;
+        const int gx = bx / 2 + hx, gy = by / 2 + hy;
+        if (gx < ow1 && gy < oh1) level1[gx + gy * ow1] = v;
+    }
+    __syncthreads();
+    if (tid < (PRE_TX / 4) * (PRE_TY / 4)) {
+        const int qx = tid % (PRE_TX / 4), qy = tid / (PRE_TX / 4);
+        const float v = half_sample_2x2(f1[2 * qy][2 * qx], f1[2 * qy][2 * qx + 1], f1[2 * qy + 1][2 * qx],
+                                        f1[2 * qy + 1][2 * qx + 1], pyramid_e_d);
+        const int gx = bx / 4 + qx, gy = by / 4 + qy;
+        if (gx < ow2 && gy < oh2) level2[gx + gy * ow2] = v;
+    }
 }
 
 static BilateralConst bilateral_const() {
@@ -84,15 +125,21 @@ static BilateralConst bilateral_const() {
 }
 
 hipError_t launch_preprocess(float *raw, float *filtered, int ow, int oh, const void *in, bool in_is_u16,
-                             int iw, int ratio, float divisor, hipStream_t s) {
+                             int iw, int ratio, float divisor, float *level1, float *level2, float pyramid_e_d,
+                             hipStream_t s) {
     const dim3 grid((ow + PRE_TX - 1) / PRE_TX, (oh + PRE_TY - 1) / PRE_TY);
     const BilateralConst bc = bilateral_const();
-    if (in_is_u16)
-        hipLaunchKernelGGL(k_preprocess<true>, grid, dim3(256), 0, s, raw, filtered, ow, oh, in, iw, ratio,
-                           divisor, bc);
+    const bool pyramid = level1 != nullptr && level2 != nullptr;
+    if (pyramid && (!filtered || !in_is_u16 || ow % 4 != 0 || oh % 4 != 0)) return hipErrorInvalidValue;
+    if (pyramid)
+        hipLaunchKernelGGL((k_preprocess<true, true>), grid, dim3(256), 0, s, raw, filtered, ow, oh, in, iw, ratio,
+                           divisor, bc, level1, level2, pyramid_e_d);
+    else if (in_is_u16)
+        hipLaunchKernelGGL((k_preprocess<true, false>), grid, dim3(256), 0, s, raw, filtered, ow, oh, in, iw, ratio,
+                           divisor, bc, level1, level2, pyramid_e_d);
     else
-        hipLaunchKernelGGL(k_preprocess<false>, grid, dim3(256), 0, s, raw, filtered, ow, oh, in, iw, ratio,
-                           divisor, bc);
+        hipLaunchKernelGGL((k_preprocess<false, false>), grid, dim3(256), 0, s, raw, filtered, ow, oh, in, iw, ratio,
+                           divisor, bc, level1, level2, pyramid_e_d);
     return hipGetLastError();
 }
 
@@ -108,14 +155,7 @@ __global__ __launch_bounds__(256) void k_half_sample(float *__restrict__ out, co
     const int cx = 2 * x, cy = 2 * y;
     const float2 top = *reinterpret_cast<const float2 *>(in + cx + cy * iw);
     const float2 bot = *reinterpret_cast<const float2 *>(in + cx + (cy + 1) * iw);
-    const float center = top.x;
-    float sum = 0.0f, t = 0.0f;
-    // upstream order: i (row) outer, j (column) inner
-    if (fabsf(top.x - center) < e_d) { sum += 1.0f; t += top.x; }
-    if (fabsf(top.y - center) < e_d) { sum += 1.0f; t += top.y; }
-    if (fabsf(bot.x - center) < e_d) { sum += 1.0f; t += bot.x; }
-    if (fabsf(bot.y - center) < e_d) { sum += 1.0f; t += bot.y; }
-    out[x + y * ow] = t / sum;
+    out[x + y * ow] = half_sample_2x2(top.x, top.y, bot.x, bot.y, e_d);
 }
 
 hipError_t launch_half_sample(float *out, const float *in, int iw, int ih, float e_d, hipStream_t s) {
@@ -678,10 +718,11 @@ __device__ inline float div_shared(float n, float d, float r1) {
     return fmaf(fmaf(-d, q1, n), r1, q1);
 }
 
+template <int PW>
 struct IcpShared {
-    float slots[KFH_TRACK_THREADS * 4];        // row slots of the pending sum, [slot][32]
+    float slots[64 * (1 + PW) * 4];            // row slots of the pending sum, [slot][32]
     float sums[32];                            // reduction of the last finalised iteration
-    float part[KFH_TRACK_PIXEL_WAVES][32];     // this iteration's sums per pixel wavefront
+    float part[PW][32];                        // this iteration's sums per pixel wavefront
     Mat4 pose;
     int done_mask, iterations, slow_solves;
 };
@@ -721,7 +762,8 @@ __device__ inline void icp_finalize_wave0(const IcpState *__restrict__ in, Mat4 
 }
 
 // one wavefront of block 0: lanes 0..31 store the sums, lane 0 the rest
-__device__ inline void icp_store_state(IcpState *out, const IcpShared &sh, int pending_nblocks, int level,
+template <int PW>
+__device__ inline void icp_store_state(IcpState *out, const IcpShared<PW> &sh, int pending_nblocks, int level,
                                        int last_iter) {
     const int lane = threadIdx.x & 63;
     if (lane < 32) out->sums[lane] = sh.sums[lane];
@@ -813,19 +855,22 @@ __device__ inline float wave_reduce32(float (&v)[32]) {
 // pixel wavefronts project their pixels with the pose of BEFORE that update and gather the model map there
 // (the update moves few projections across a pixel boundary), and compute the input normals.  With the new
 // pose only pixels whose reference index changed are gathered again.
-template <bool PACKED, int PPT>
-__global__ __launch_bounds__(KFH_TRACK_THREADS) void k_icp_iteration(IcpIterArgs a) {
-    __shared__ IcpShared sh;
+template <bool PACKED, int PW, int PPT>
+__global__ __launch_bounds__(64 * (1 + PW)) void k_icp_iteration(IcpIterArgs a) {
+    constexpr int NT = 64 * (1 + PW);
+    __shared__ IcpShared<PW> sh;
     KFH_STAMP(0, 0);
+    if (a.stamps != nullptr && threadIdx.x == 0 && blockIdx.x < KFH_STAMP_BLOCKS && a.seq < KFH_STAMP_LAUNCHES)
+        a.stamps[((size_t)a.seq * KFH_STAMP_BLOCKS + blockIdx.x) * KFH_STAMP_SLOTS + 12] = __builtin_amdgcn_s_memtime();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int pw = wave - 1;                          // pixel wavefront index; wavefront 0 has no pixels
     const IcpState *in = &a.ctrl->icp[a.seq & 1];
     IcpState *out = &a.ctrl->icp[(a.seq + 1) & 1];
 
-    PartialRows<KFH_TRACK_THREADS> pr;
-    load_partial_rows<KFH_TRACK_THREADS>(pr, a.partials_in, a.pending_rows);
+    PartialRows<NT> pr;
+    load_partial_rows<NT>(pr, a.partials_in, a.pending_rows);
 
-    const int tile_h = KFH_TRACK_PIXEL_WAVES * PPT;
+    const int tile_h = PW * PPT;
     const int tiles_x = (a.iw + KFH_TRACK_TILE_W - 1) / KFH_TRACK_TILE_W;
     const int tile_y = blockIdx.x / tiles_x, tile_x = blockIdx.x - tile_y * tiles_x;
     const int x_raw = tile_x * KFH_TRACK_TILE_W + lane;
@@ -883,7 +928,7 @@ __global__ __launch_bounds__(KFH_TRACK_THREADS) void k_icp_iteration(IcpIterArgs
         }
         return;
     }
-    if (pend > 0) stage_partial_rows<KFH_TRACK_THREADS>(sh.slots, pr, a.partials_in, pend);
+    if (pend > 0) stage_partial_rows<NT>(sh.slots, pr, a.partials_in, pend);
     __syncthreads();
     KFH_STAMP(1, 0);
 
@@ -892,7 +937,7 @@ __global__ __launch_bounds__(KFH_TRACK_THREADS) void k_icp_iteration(IcpIterArgs
     float4 rsa[PPT], rsb[PPT];                        // gathered model map (PACKED: rsa = {t, normal})
     unsigned sidx[PPT];
     if (wave == 0) {
-        icp_finalize_wave0<KFH_TRACK_THREADS>(in, pose_old, pend, a.icp_threshold, sh.slots, sh.sums, &sh.pose,
+        icp_finalize_wave0<NT>(in, pose_old, pend, a.icp_threshold, sh.slots, sh.sums, &sh.pose,
                                               &sh.done_mask, &sh.iterations, &sh.slow_solves);
     } else {
         // Branch-free on purpose: the PPT pixels are independent dependency chains (divisions, square
@@ -1079,12 +1124,14 @@ __global__ __launch_bounds__(KFH_TRACK_THREADS) void k_icp_iteration(IcpIterArgs
         if (lane < 32) {
             float t = sh.part[0][lane];
 #pragma unroll
-            for (int w = 1; w < KFH_TRACK_PIXEL_WAVES; ++w) t += sh.part[w][lane];
+            for (int w = 1; w < PW; ++w) t += sh.part[w][lane];
             a.partials_out[blockIdx.x * 32 + lane] = t;
         }
         if (blockIdx.x == 0) icp_store_state(out, sh, gridDim.x, a.level, a.last_iter);
     }
     KFH_STAMP(6, 0);
+    if (a.stamps != nullptr && threadIdx.x == 0 && blockIdx.x < KFH_STAMP_BLOCKS && a.seq < KFH_STAMP_LAUNCHES)
+        a.stamps[((size_t)a.seq * KFH_STAMP_BLOCKS + blockIdx.x) * KFH_STAMP_SLOTS + 13] = __builtin_amdgcn_s_memtime();
 }
 
 // largest float d2 with sqrtf(d2) <= t  (sqrtf is monotonic and correctly rounded on host and device)
@@ -1096,15 +1143,16 @@ static float max_arg_with_sqrt_le(float t) {
     return c;
 }
 
-template <bool PACKED>
-static void launch_icp_ppt(const IcpIterArgs &a, int ppt, int nb, hipStream_t s) {
-    const dim3 g(nb), b(KFH_TRACK_THREADS);
-    switch (ppt) {
-        case 1: hipLaunchKernelGGL((k_icp_iteration<PACKED, 1>), g, b, 0, s, a); break;
-        case 2: hipLaunchKernelGGL((k_icp_iteration<PACKED, 2>), g, b, 0, s, a); break;
-        case 3: hipLaunchKernelGGL((k_icp_iteration<PACKED, 3>), g, b, 0, s, a); break;
-        case 5: hipLaunchKernelGGL((k_icp_iteration<PACKED, 5>), g, b, 0, s, a); break;
-        default: hipLaunchKernelGGL((k_icp_iteration<PACKED, 8>), g, b, 0, s, a); break;
+template <bool PACKED, int PW>
+static bool launch_icp_ppt(const IcpIterArgs &a, int nb, hipStream_t s) {
+    const dim3 g(nb), b(64 * (1 + PW));
+    switch (a.ppt) {
+        case 1: hipLaunchKernelGGL((k_icp_iteration<PACKED, PW, 1>), g, b, 0, s, a); return true;
+        case 2: hipLaunchKernelGGL((k_icp_iteration<PACKED, PW, 2>), g, b, 0, s, a); return true;
+        case 3: hipLaunchKernelGGL((k_icp_iteration<PACKED, PW, 3>), g, b, 0, s, a); return true;
+        case 5: hipLaunchKernelGGL((k_icp_iteration<PACKED, PW, 5>), g, b, 0, s, a); return true;
+        case 8: hipLaunchKernelGGL((k_icp_iteration<PACKED, PW, 8>), g, b, 0, s, a); return true;
+        default: return false;
     }
 }
 
@@ -1113,16 +1161,19 @@ hipError_t launch_icp_iteration(const IcpIterArgs &a_in, hipStream_t s) {
     const bool packed = a.ref_vertex == nullptr;
     if (packed && (a.in_normal != nullptr || a.ref_tn == nullptr || a.track_out != nullptr)) return hipErrorInvalidValue;
     if (!packed && (a.in_normal == nullptr || a.ref_normal == nullptr)) return hipErrorInvalidValue;
-    if (a.ppt == 0) a.ppt = track_ppt(a.iw, a.ih, a.max_blocks > 0 ? a.max_blocks : 256);
-    if (a.ppt != 1 && a.ppt != 2 && a.ppt != 3 && a.ppt != 5 && a.ppt != 8) return hipErrorInvalidValue;
+    if (a.pw == 0 || a.ppt == 0) track_shape(a.iw, a.ih, a.max_blocks > 0 ? a.max_blocks : 256, &a.pw, &a.ppt);
     a.dist2_max = max_arg_with_sqrt_le(a.dist_threshold);
     {
         const Mat4 ik = inverse_camera_matrix(a.k[0], a.k[1], a.k[2], a.k[3]);
         a.ik[0] = ik.m[0]; a.ik[1] = ik.m[2]; a.ik[2] = ik.m[5]; a.ik[3] = ik.m[6];
     }
-    const int nb = track_blocks(a.iw, a.ih, a.ppt);
-    if (packed) launch_icp_ppt<true>(a, a.ppt, nb, s);
-    else launch_icp_ppt<false>(a, a.ppt, nb, s);
+    const int nb = track_blocks(a.iw, a.ih, a.pw, a.ppt);
+    bool ok = false;
+    if (packed && a.pw == 4) ok = launch_icp_ppt<true, 4>(a, nb, s);
+    else if (packed && a.pw == 8) ok = launch_icp_ppt<true, 8>(a, nb, s);
+    else if (!packed && a.pw == 4) ok = launch_icp_ppt<false, 4>(a, nb, s);
+    else if (!packed && a.pw == 8) ok = launch_icp_ppt<false, 8>(a, nb, s);
+    if (!ok) return hipErrorInvalidValue;
     return hipGetLastError();
 }
 
@@ -1196,7 +1247,7 @@ hipError_t launch_track_reduce(Ctrl *scratch_ctrl, float *partials, float *sums,
     a.partials_out = partials;
     a.pending_rows = 0;
     a.ref_tn = nullptr;
-    a.ppt = track_ppt(iw, ih, 256);
+    track_shape(iw, ih, 256, &a.pw, &a.ppt);
     a.max_blocks = 256;
     a.seq = 0;
     a.level = 0;
@@ -1210,7 +1261,7 @@ hipError_t launch_track_reduce(Ctrl *scratch_ctrl, float *partials, float *sums,
     a.stamps = nullptr;
     hipError_t e = launch_icp_iteration(a, s);
     if (e != hipSuccess) return e;
-    return launch_sum_partials(sums, partials, track_blocks(iw, ih, a.ppt), s);
+    return launch_sum_partials(sums, partials, track_blocks(iw, ih, a.pw, a.ppt), s);
 }
 
 __global__ void k_update_pose(float *pose16, double *x6, int *converged, const float *sums, float thr) {

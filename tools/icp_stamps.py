@@ -15,7 +15,7 @@ from slambench_amd import native, synth
 from slambench_amd.config import KFusionConfig, TUM_FR1_DEPTH_INTRINSICS
 from slambench_amd.kfusion import KFusion
 
-LAUNCHES, BLOCKS, SLOTS = 64, 320, 12
+LAUNCHES, BLOCKS, SLOTS = 64, 320, 14
 cfg = KFusionConfig(intrinsics=TUM_FR1_DEPTH_INTRINSICS, volume_resolution=(512,) * 3)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 depth, gt, ts = synth.make_sequence(n, seed=1, intrinsics=TUM_FR1_DEPTH_INTRINSICS, noise=True)
@@ -45,10 +45,14 @@ for q in range(19):
         v = r[:, s_]
         v = v[v >= t0]
         cols.append(((np.median(v) - t0) / 100.0, (v.max() - t0) / 100.0) if v.size else (float("nan"),) * 2)
-    end = r[r >= t0].max()
+    end = r[:, :12][r[:, :12] >= t0].max()
     print("%4d %6d %9.2f %6.2f |" % (q, act.sum(), (t0 - t_frame) / 100.0,
                                     (t0 - prev_end) / 100.0 if prev_end else 0.0)
           + " |".join(" %5.2f %5.2f" % c for c in cols))
     prev_end = end
+    ok = (r[:, 13] > r[:, 12]) & (r[:, 6] > r[:, 0])
+    if ok.any():
+        clk = (r[ok, 13] - r[ok, 12]) / ((r[ok, 6] - r[ok, 0]) / 100.0)   # shader cycles per microsecond
+        print("        shader clock inside this launch: median %.0f MHz (min %.0f, max %.0f)" % (np.median(clk), clk.min(), clk.max()))
 st_ = kf.status(n - 1)
 print("iterations", st_["icp_iterations"], "tracked", st_["tracked"])
