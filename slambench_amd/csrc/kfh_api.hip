@@ -64,8 +64,20 @@ struct kfh_context {
     uint16_t *h_depth_pinned = nullptr;
     uint16_t *d_depth_in = nullptr;        // staging owned by the context
     const uint16_t *d_depth_cur = nullptr; // frame to process (staging or caller-owned)
+    // Depth images of the frame being processed: aliases of one of two buffer sets.  With `overlap` the
+    // preprocessing of frame n + 1 runs on its own stream and writes the other set while frame n is still
+    // tracking / integrating.
     float *d_float_depth = nullptr;
     float *d_scaled[3] = {nullptr, nullptr, nullptr};
+    float *set_float_depth[2] = {nullptr, nullptr};
+    float *set_scaled[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
+    int next_set = 0;
+    hipStream_t pre_stream = nullptr;
+    hipEvent_t ev_pre_done = nullptr;      // recorded on pre_stream after each preprocessing launch
+    hipEvent_t ev_set_free[2] = {nullptr, nullptr};   // recorded on the main stream when a frame is done with its set
+    int cur_set = 0;
+    bool pre_pending = false;              // the main stream has not yet waited for ev_pre_done
+    bool overlap = false;
     float4 *d_in_vertex[3] = {nullptr, nullptr, nullptr};
     float4 *d_in_normal[3] = {nullptr, nullptr, nullptr};
     float4 *d_vertex = nullptr, *d_normal = nullptr;
@@ -121,7 +133,9 @@ hipError_t dev_alloc(T **p, size_t count) {
 
 void free_all(kfh_context *c) {
     if (c->h_depth_pinned) (void)hipHostFree(c->h_depth_pinned);
-    void *bufs[] = {c->d_depth_in, c->d_float_depth, c->d_scaled[0], c->d_scaled[1], c->d_scaled[2],
+    void *bufs[] = {c->d_depth_in, c->set_float_depth[0], c->set_float_depth[1], c->set_scaled[0][0],
+                    c->set_scaled[0][1], c->set_scaled[0][2], c->set_scaled[1][0], c->set_scaled[1][1],
+                    c->set_scaled[1][2],
                     c->d_in_vertex[0], c->d_in_vertex[1], c->d_in_vertex[2], c->d_in_normal[0],
                     c->d_in_normal[1], c->d_in_normal[2], c->d_vertex, c->d_normal, c->d_ray_t, c->d_volume, c->d_ref_tn, c->d_ray_tasks, c->d_integrate_boxes,
                     c->d_partials, c->d_ctrl, c->d_status, c->d_stamps};
@@ -133,11 +147,33 @@ void free_all(kfh_context *c) {
                 if (c->ev[i][j]) (void)hipEventDestroy(c->ev[i][j]);
         delete[] c->ev;
     }
+    if (c->ev_pre_done) (void)hipEventDestroy(c->ev_pre_done);
+    for (int i = 0; i < 2; ++i)
+        if (c->ev_set_free[i]) (void)hipEventDestroy(c->ev_set_free[i]);
+    if (c->pre_stream) (void)hipStreamDestroy(c->pre_stream);
     if (c->stream) (void)hipStreamDestroy(c->stream);
+}
+
+// The main stream must not touch the depth images before the preprocessing launch that fills them is done.
+hipError_t ensure_pre_done(kfh_context *c) {
+    if (!c->pre_pending) return hipSuccess;
+    c->pre_pending = false;
+    return hipStreamWaitEvent(c->stream, c->ev_pre_done, 0);
+}
+
+void select_set(kfh_context *c, int set) {
+    c->cur_set = set;
+    c->d_float_depth = c->set_float_depth[set];
+    for (int l = 0; l < 3; ++l) c->d_scaled[l] = c->set_scaled[set][l];
 }
 
 int init_state(kfh_context *c) {
     const size_t npix = (size_t)c->w * c->h;
+    KFH_HIP(hipStreamSynchronize(c->pre_stream));
+    KFH_HIP(hipStreamSynchronize(c->stream));
+    c->pre_pending = false;
+    c->next_set = 0;
+    select_set(c, 0);
     KFH_HIP(launch_fill_volume(c->d_volume, c->volume_voxels, c->stream));
     KFH_HIP(hipMemsetAsync(c->d_vertex, 0, npix * sizeof(float4), c->stream));
     KFH_HIP(hipMemsetAsync(c->d_normal, 0, npix * sizeof(float4), c->stream));
@@ -219,10 +255,19 @@ int kfh_create(const kfh_config *cfg, kfh_context **out) {
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&c->h_depth_pinned), nin * sizeof(uint16_t), hipHostMallocDefault);
     if (e == hipSuccess) e = dev_alloc(&c->d_depth_in, nin);
-    if (e == hipSuccess) e = dev_alloc(&c->d_float_depth, npix);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->pre_stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_pre_done, hipEventDisableTiming);
+    for (int i = 0; i < 2 && e == hipSuccess; ++i) {
+        e = hipEventCreateWithFlags(&c->ev_set_free[i], hipEventDisableTiming);
+        if (e == hipSuccess) e = dev_alloc(&c->set_float_depth[i], npix);
+    }
+    // Opt-in: on MI355X the cross-stream event waits this needs cost more per frame (about 20 us measured)
+    // than the 13 us preprocessing launch they hide, so a single stream is the default.
+    c->overlap = std::getenv("KFH_OVERLAP_PREPROCESS") != nullptr;
     for (int l = 0; l < 3 && e == hipSuccess; ++l) {
         const size_t nl = (size_t)(c->w >> l) * (c->h >> l);
-        e = dev_alloc(&c->d_scaled[l], nl);
+        e = dev_alloc(&c->set_scaled[0][l], nl);
+        if (e == hipSuccess) e = dev_alloc(&c->set_scaled[1][l], nl);
         if (e == hipSuccess) e = dev_alloc(&c->d_in_vertex[l], nl);
         if (e == hipSuccess) e = dev_alloc(&c->d_in_normal[l], nl);
     }
@@ -272,6 +317,7 @@ int kfh_create(const kfh_config *cfg, kfh_context **out) {
 
 int kfh_destroy(kfh_context *c) {
     if (!c) return KFH_OK;
+    if (c->pre_stream) (void)hipStreamSynchronize(c->pre_stream);
     (void)hipStreamSynchronize(c->stream);
     free_all(c);
     delete c;
@@ -286,10 +332,12 @@ int kfh_reset(kfh_context *c) {
 int kfh_upload_depth(kfh_context *c, const uint16_t *h_depth) {
     KFH_REQUIRE(c != nullptr && h_depth != nullptr, "NULL argument");
     const size_t bytes = (size_t)c->cfg.input_width * c->cfg.input_height * sizeof(uint16_t);
-    // the pinned buffer may still feed the previous frame's copy
-    KFH_HIP(hipStreamSynchronize(c->stream));
+    // The copy goes on the stream that preprocesses: the pinned buffer may still feed the previous frame's copy
+    // and the device staging buffer the previous frame's preprocessing launch.
+    hipStream_t ps = c->overlap ? c->pre_stream : c->stream;
+    KFH_HIP(hipStreamSynchronize(ps));
     std::memcpy(c->h_depth_pinned, h_depth, bytes);
-    KFH_HIP(hipMemcpyAsync(c->d_depth_in, c->h_depth_pinned, bytes, hipMemcpyHostToDevice, c->stream));
+    KFH_HIP(hipMemcpyAsync(c->d_depth_in, c->h_depth_pinned, bytes, hipMemcpyHostToDevice, ps));
     c->d_depth_cur = c->d_depth_in;
     return KFH_OK;
 }
@@ -302,18 +350,32 @@ int kfh_set_depth_device(kfh_context *c, const uint16_t *d_depth) {
 
 int kfh_preprocess(kfh_context *c) {
     KFH_REQUIRE(c != nullptr, "context is NULL");
-    if (c->timing == 1) KFH_HIP(hipEventRecord(c->ev[c->frame % KFH_TIMING_RING][0], c->stream));
+    // With phase timing on, everything runs on the main stream so that the four phases do not overlap.
+    const bool side = c->overlap && c->timing != 1;
+    hipStream_t ps = side ? c->pre_stream : c->stream;
+    const int set = c->next_set;
+    c->next_set ^= 1;
+    KFH_HIP(ensure_pre_done(c));
+    select_set(c, set);
+    // frame n - 2 used this set: its tracking and integration must be done before it is overwritten
+    if (side) KFH_HIP(hipStreamWaitEvent(ps, c->ev_set_free[set], 0));
+    if (c->timing == 1) KFH_HIP(hipEventRecord(c->ev[c->frame % KFH_TIMING_RING][0], ps));
     // the depth pyramid of tracking (halfSampleRobustImageKernel twice) is produced by the same launch
     KFH_HIP(launch_preprocess(c->d_float_depth, c->d_scaled[0], c->w, c->h, c->d_depth_cur, true,
                               c->cfg.input_width, c->cfg.compute_size_ratio, c->cfg.depth_divisor, c->d_scaled[1],
-                              c->d_scaled[2], E_DELTA * 3, c->stream));
+                              c->d_scaled[2], E_DELTA * 3, ps));
     c->depth_version++;
-    if (c->timing == 1) KFH_HIP(hipEventRecord(c->ev[c->frame % KFH_TIMING_RING][1], c->stream));
+    if (c->timing == 1) KFH_HIP(hipEventRecord(c->ev[c->frame % KFH_TIMING_RING][1], ps));
+    if (side) {
+        KFH_HIP(hipEventRecord(c->ev_pre_done, ps));
+        c->pre_pending = true;
+    }
     return KFH_OK;
 }
 
 int kfh_track(kfh_context *c) {
     KFH_REQUIRE(c != nullptr, "context is NULL");
+    KFH_HIP(ensure_pre_done(c));
     int total_iterations = 0;
     for (int l = 0; l < 3; ++l) total_iterations += c->cfg.pyramid[l];
     if (c->frame % c->cfg.tracking_rate != 0 || total_iterations == 0) {
@@ -358,6 +420,7 @@ int kfh_track(kfh_context *c) {
 
 int kfh_integrate(kfh_context *c) {
     KFH_REQUIRE(c != nullptr, "context is NULL");
+    KFH_HIP(ensure_pre_done(c));
     if ((c->frame % c->cfg.integration_rate) == 0 || c->frame <= 3) {
         const float *src = c->cfg.integrate_filtered ? c->d_scaled[0] : c->d_float_depth;
         // planes [zs0, zs1) are stored; the kernel replays the z < zs0 steps of each column arithmetically
@@ -419,6 +482,8 @@ int kfh_composite_slabs(kfh_context *c, const float *d_t, const void *d_vertex, 
 
 int kfh_end_frame(kfh_context *c) {
     KFH_REQUIRE(c != nullptr, "context is NULL");
+    KFH_HIP(ensure_pre_done(c));
+    KFH_HIP(hipEventRecord(c->ev_set_free[c->cur_set], c->stream));   // this frame is done with its depth images
     c->frame++;
     return KFH_OK;
 }
@@ -433,6 +498,7 @@ int kfh_process_frame(kfh_context *c) {
 
 int kfh_sync(kfh_context *c) {
     KFH_REQUIRE(c != nullptr, "context is NULL");
+    KFH_HIP(hipStreamSynchronize(c->pre_stream));
     KFH_HIP(hipStreamSynchronize(c->stream));
     return KFH_OK;
 }
@@ -480,6 +546,7 @@ int kfh_device_ptr(kfh_context *c, int buffer, int level, void **d_ptr, size_t *
     KFH_REQUIRE(level >= 0 && level < 3, "level %d out of range", level);
     const size_t npix = (size_t)c->w * c->h;
     const size_t nl = (size_t)(c->w >> level) * (c->h >> level);
+    KFH_HIP(ensure_pre_done(c));     // the depth images may still be in the making on the other stream
     switch (buffer) {
         case KFH_BUF_FLOAT_DEPTH: *d_ptr = c->d_float_depth; *bytes = npix * sizeof(float); break;
         case KFH_BUF_SCALED_DEPTH: *d_ptr = c->d_scaled[level]; *bytes = nl * sizeof(float); break;
