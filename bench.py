@@ -113,7 +113,7 @@ def main():
     else:
         kf = KFusion(cfg)
         step = kf.process_frame
-    kf.set_timing(2)     # two HIP events per frame around the integration phase, on the pipeline's stream
+    kf.set_timing(3)     # two HIP events around the integration phase of every 16th frame, on the pipeline's stream
 
     def barrier():
         if world > 1:
@@ -143,7 +143,7 @@ def main():
     for f in range(first, total):
         st = kf.status(f)
         tracked += int(st["tracked"])
-        if st["integrated"]:
+        if st["integrated"] and f % 16 == 0:
             integ_ms.append(float(kf.phase_ms(f)[2]))
     integ_ms = np.asarray(integ_ms)
     t_int = float(integ_ms.mean()) * 1e-3 if integ_ms.size else float("nan")

@@ -89,7 +89,10 @@ enum kfh_buffer {
     KFH_BUF_MODEL_VERTEX = 4,  /* float4[h][w]           raycast output                 */
     KFH_BUF_MODEL_NORMAL = 5,  /* float4[h][w]                                          */
     KFH_BUF_VOLUME = 6,        /* short2[slab_z1-slab_z0][Y][X]                         */
-    KFH_BUF_RAY_T = 7          /* float[h][w]            hit distance of the last raycast */
+    KFH_BUF_RAY_T = 7,         /* float[h][w]            hit distance of the last raycast */
+    KFH_BUF_BRICK_MARKS = 8    /* uint8[Z/8][Y/8][X/8]   1: no voxel of the 8^3 brick (and one voxel past it per axis) has
+                                  been below 26300/32766 since the last reset; the raycast skips such bricks with its
+                                  coarse step.  Unsharded contexts only. */
 };
 
 const char *kfh_last_error(void);
@@ -124,7 +127,8 @@ int kfh_download(kfh_context *ctx, int buffer, int level, void *h_dst, size_t by
 int kfh_device_ptr(kfh_context *ctx, int buffer, int level, void **d_ptr, size_t *bytes);
 int kfh_stream(kfh_context *ctx, void **stream);
 /* HIP-event timing on the context's stream.  mode 0: off; 1: all four phases of every frame;
- * 2: the integration phase only (two events per frame).  Records of the last 512 frames are kept;
+ * 2: the integration phase only (two events per frame); 3: as 2 but only on frames whose index is a
+ * multiple of 16 (an event record occupies the stream for a few microseconds).  Records of the last 512 frames are kept;
  * ms = {preprocessing, tracking, integration, raycasting}; both getters synchronise. */
 int kfh_set_timing(kfh_context *ctx, int mode);
 int kfh_phase_ms(kfh_context *ctx, float ms[4]);                 /* most recent frame */

@@ -81,6 +81,7 @@ struct kfh_context {
     float4 *d_in_vertex[3] = {nullptr, nullptr, nullptr};
     float4 *d_in_normal[3] = {nullptr, nullptr, nullptr};
     float4 *d_vertex = nullptr, *d_normal = nullptr;
+    unsigned char *d_bricks = nullptr;     // brick marks for the raycast (null when the volume is sharded)
     unsigned *d_integrate_boxes = nullptr; // boxes the integrate plan launch kept for the work launch
     void *d_ray_tasks = nullptr;           // rays handed from the first raycast pass to the second
     float4 *d_ref_tn = nullptr;            // packed model map {hit distance, normal}: what tracking gathers
@@ -137,7 +138,7 @@ void free_all(kfh_context *c) {
                     c->set_scaled[0][1], c->set_scaled[0][2], c->set_scaled[1][0], c->set_scaled[1][1],
                     c->set_scaled[1][2],
                     c->d_in_vertex[0], c->d_in_vertex[1], c->d_in_vertex[2], c->d_in_normal[0],
-                    c->d_in_normal[1], c->d_in_normal[2], c->d_vertex, c->d_normal, c->d_ray_t, c->d_volume, c->d_ref_tn, c->d_ray_tasks, c->d_integrate_boxes,
+                    c->d_in_normal[1], c->d_in_normal[2], c->d_vertex, c->d_normal, c->d_ray_t, c->d_volume, c->d_ref_tn, c->d_ray_tasks, c->d_integrate_boxes, c->d_bricks,
                     c->d_partials, c->d_ctrl, c->d_status, c->d_stamps};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
@@ -153,6 +154,9 @@ void free_all(kfh_context *c) {
     if (c->pre_stream) (void)hipStreamDestroy(c->pre_stream);
     if (c->stream) (void)hipStreamDestroy(c->stream);
 }
+
+// Event records cost a few microseconds of stream time each; mode 3 only takes them on every sixteenth frame.
+bool timed_frame(const kfh_context *c) { return c->timing != 0 && (c->timing != 3 || c->frame % 16 == 0); }
 
 // The main stream must not touch the depth images before the preprocessing launch that fills them is done.
 hipError_t ensure_pre_done(kfh_context *c) {
@@ -175,6 +179,7 @@ int init_state(kfh_context *c) {
     c->next_set = 0;
     select_set(c, 0);
     KFH_HIP(launch_fill_volume(c->d_volume, c->volume_voxels, c->stream));
+    if (c->d_bricks) KFH_HIP(hipMemsetAsync(c->d_bricks, 1, brick_mark_bytes(c->cfg.vol_res), c->stream));
     KFH_HIP(hipMemsetAsync(c->d_vertex, 0, npix * sizeof(float4), c->stream));
     KFH_HIP(hipMemsetAsync(c->d_normal, 0, npix * sizeof(float4), c->stream));
     KFH_HIP(hipMemsetAsync(c->d_ray_t, 0, npix * sizeof(float), c->stream));
@@ -278,6 +283,8 @@ int kfh_create(const kfh_config *cfg, kfh_context **out) {
     if (e == hipSuccess) e = hipMalloc(&c->d_ray_tasks, raycast_task_bytes(c->w, c->h));
     if (e == hipSuccess)
         e = hipMalloc(reinterpret_cast<void **>(&c->d_integrate_boxes), integrate_box_list_bytes(cfg->vol_res, c->zs1));
+    if (e == hipSuccess && !c->sharded && std::getenv("KFH_NO_BRICK_MARKS") == nullptr)
+        e = hipMalloc(reinterpret_cast<void **>(&c->d_bricks), brick_mark_bytes(cfg->vol_res));
     if (e == hipSuccess) e = dev_alloc(&c->d_volume, c->volume_voxels);
     {
         hipDeviceProp_t prop;
@@ -414,7 +421,7 @@ int kfh_track(kfh_context *c) {
         }
         KFH_HIP(launch_icp_finish(finish_args(c, seq, rows), c->stream));
     }
-    if (c->timing) KFH_HIP(hipEventRecord(c->ev[c->frame % KFH_TIMING_RING][2], c->stream));
+    if (timed_frame(c)) KFH_HIP(hipEventRecord(c->ev[c->frame % KFH_TIMING_RING][2], c->stream));
     return KFH_OK;
 }
 
@@ -427,11 +434,11 @@ int kfh_integrate(kfh_context *c) {
         KFH_HIP(launch_integrate(c->d_volume, c->cfg.vol_res, c->cfg.vol_dim, c->zs0, c->zs1, src, c->w, c->h,
                                  &c->d_ctrl->inv_pose, camera_matrix(c->k[0], c->k[1], c->k[2], c->k[3]),
                                  c->cfg.mu, MAX_WEIGHT, &c->d_ctrl->integrate_gate, c->d_integrate_boxes,
-                                 &c->d_ctrl->integrate_box_count, c->stream));
+                                 &c->d_ctrl->integrate_box_count, c->d_bricks, c->stream));
     }
-    if (c->timing) {
+    if (timed_frame(c)) {
         KFH_HIP(hipEventRecord(c->ev[c->frame % KFH_TIMING_RING][3], c->stream));
-        if (c->timing == 2 && c->timed_first < 0) c->timed_first = c->frame;
+        if (c->timing >= 2 && c->timed_first < 0) c->timed_first = c->frame;
     }
     return KFH_OK;
 }
@@ -450,7 +457,7 @@ int kfh_raycast(kfh_context *c) {
         KFH_HIP(launch_raycast(c->d_vertex, c->d_normal, c->d_ray_t, c->d_ref_tn, c->w, c->h, c->d_volume,
                                c->cfg.vol_res, c->cfg.vol_dim, 0, c->cfg.vol_res[2], &c->d_ctrl->view, NEAR_PLANE, FAR_PLANE,
                                raycast_step(c->cfg), 0.75f * c->cfg.mu, c->d_ray_tasks,
-                               &c->d_ctrl->ray_task_count, c->stream));
+                               &c->d_ctrl->ray_task_count, c->d_bricks, c->stream));
     }
     if (c->timing == 1) {
         KFH_HIP(hipEventRecord(c->ev[c->frame % KFH_TIMING_RING][4], c->stream));
@@ -465,7 +472,7 @@ int kfh_raycast_slab(kfh_context *c) {
         KFH_HIP(launch_raycast(c->d_vertex, c->d_normal, c->d_ray_t, nullptr, c->w, c->h, c->d_volume,
                                c->cfg.vol_res, c->cfg.vol_dim, c->cfg.slab_z0, c->cfg.slab_z1, &c->d_ctrl->view, NEAR_PLANE,
                                FAR_PLANE, raycast_step(c->cfg), 0.75f * c->cfg.mu, c->d_ray_tasks,
-                               &c->d_ctrl->ray_task_count, c->stream));
+                               &c->d_ctrl->ray_task_count, nullptr, c->stream));
     }
     return KFH_OK;
 }
@@ -567,6 +574,11 @@ int kfh_device_ptr(kfh_context *c, int buffer, int level, void **d_ptr, size_t *
         case KFH_BUF_MODEL_NORMAL: *d_ptr = c->d_normal; *bytes = npix * sizeof(float4); break;
         case KFH_BUF_VOLUME: *d_ptr = c->d_volume; *bytes = c->volume_voxels * sizeof(short2); break;
         case KFH_BUF_RAY_T: *d_ptr = c->d_ray_t; *bytes = npix * sizeof(float); break;
+        case KFH_BUF_BRICK_MARKS:
+            if (!c->d_bricks) return fail(KFH_ERR_STATE, "this context keeps no brick marks (sharded volume)");
+            *d_ptr = c->d_bricks;
+            *bytes = brick_mark_bytes(c->cfg.vol_res);
+            break;
         default: return fail(KFH_ERR_INVALID_ARG, "unknown buffer id %d", buffer);
     }
     return KFH_OK;
@@ -591,7 +603,7 @@ int kfh_stream(kfh_context *c, void **stream) {
 
 int kfh_set_timing(kfh_context *c, int mode) {
     KFH_REQUIRE(c != nullptr, "context is NULL");
-    KFH_REQUIRE(mode >= 0 && mode <= 2, "timing mode must be 0, 1 or 2");
+    KFH_REQUIRE(mode >= 0 && mode <= 3, "timing mode must be 0, 1, 2 or 3");
     if (mode != 0 && !c->ev) {
         c->ev = new (std::nothrow) hipEvent_t[KFH_TIMING_RING][5]();
         if (!c->ev) return fail(KFH_ERR_STATE, "out of host memory");
@@ -607,7 +619,8 @@ int kfh_phase_ms_frame(kfh_context *c, int frame, float ms[4]) {
     KFH_REQUIRE(c != nullptr && ms != nullptr, "NULL argument");
     if (!c->timing || c->timed_first < 0)
         return fail(KFH_ERR_STATE, "no frame has been processed with timing enabled");
-    KFH_REQUIRE(frame >= c->timed_first && frame < c->frame && frame >= c->frame - KFH_TIMING_RING,
+    KFH_REQUIRE(frame >= c->timed_first && frame < c->frame && frame >= c->frame - KFH_TIMING_RING &&
+                    (c->timing != 3 || frame % 16 == 0),
                 "frame %d has no retained timing record", frame);
     KFH_HIP(hipStreamSynchronize(c->stream));
     hipEvent_t *e = c->ev[frame % KFH_TIMING_RING];
@@ -625,6 +638,34 @@ int kfh_phase_ms(kfh_context *c, float ms[4]) {
     return kfh_phase_ms_frame(c, c->frame - 1, ms);
 }
 
+// Diagnostic (not part of include/kfusion_hip.h): microseconds per pose update (6x6 solve, exponential, pose
+// product) in a dependent chain on one wavefront, from two runs of different length.
+int kfh_debug_solver_us(const float *h_sums32, float *us_per_update) {
+    float *d = nullptr;
+    KFH_HIP(hipMalloc(reinterpret_cast<void **>(&d), 48 * sizeof(float)));
+    float host[48] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+    std::memcpy(host + 16, h_sums32, 32 * sizeof(float));
+    hipEvent_t e0, e1;
+    KFH_HIP(hipEventCreate(&e0));
+    KFH_HIP(hipEventCreate(&e1));
+    float ms[2] = {0, 0};
+    const int n[2] = {2000, 4000};
+    for (int rep = 0; rep < 2; ++rep)
+        for (int k = 0; k < 2; ++k) {
+            KFH_HIP(hipMemcpy(d, host, sizeof(host), hipMemcpyHostToDevice));
+            KFH_HIP(hipEventRecord(e0, nullptr));
+            KFH_HIP(launch_update_pose_chain(d, d + 16, 0.f, n[k], nullptr));
+            KFH_HIP(hipEventRecord(e1, nullptr));
+            KFH_HIP(hipEventSynchronize(e1));
+            KFH_HIP(hipEventElapsedTime(&ms[k], e0, e1));
+        }
+    *us_per_update = (ms[1] - ms[0]) * 1e3f / (float)(n[1] - n[0]);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    (void)hipFree(d);
+    return KFH_OK;
+}
+
 // Diagnostic (not part of include/kfusion_hip.h): fuse the current depth map once more (this changes the
 // volume) with per-wavefront records {start tick, end tick, candidate voxels, voxels written}.
 // h_out holds n_values = boxes * 4 wavefronts * 4 values + 1; the last one receives the number of boxes kept.
@@ -639,7 +680,7 @@ int kfh_debug_integrate_stats(kfh_context *c, unsigned long long *h_out, size_t 
     hipError_t e = launch_integrate(c->d_volume, c->cfg.vol_res, c->cfg.vol_dim, c->zs0, c->zs1, src, c->w, c->h,
                                     &c->d_ctrl->inv_pose, camera_matrix(c->k[0], c->k[1], c->k[2], c->k[3]),
                                     c->cfg.mu, MAX_WEIGHT, nullptr, c->d_integrate_boxes,
-                                    &c->d_ctrl->integrate_box_count, c->stream);
+                                    &c->d_ctrl->integrate_box_count, c->d_bricks, c->stream);
     set_integrate_debug(nullptr);
     if (e == hipSuccess) e = hipMemcpyAsync(h_out + n_values - 1, &c->d_ctrl->integrate_box_count, sizeof(unsigned),
                                             hipMemcpyDeviceToHost, c->stream);
@@ -665,7 +706,7 @@ int kfh_debug_raycast_stats(kfh_context *c, unsigned long long *h_out) {
     hipError_t e = launch_raycast(c->d_vertex, c->d_normal, c->d_ray_t, c->d_ref_tn, c->w, c->h, c->d_volume,
                                   c->cfg.vol_res, c->cfg.vol_dim, 0, c->cfg.vol_res[2], &c->d_ctrl->view, NEAR_PLANE,
                                   FAR_PLANE, raycast_step(c->cfg), 0.75f * c->cfg.mu, c->d_ray_tasks,
-                                  &c->d_ctrl->ray_task_count, c->stream);
+                                  &c->d_ctrl->ray_task_count, c->d_bricks, c->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(h_out + n, &c->d_ctrl->ray_task_count, sizeof(unsigned),
                                             hipMemcpyDeviceToHost, c->stream);
     set_raycast_debug(nullptr);
@@ -780,7 +821,7 @@ int kfh_k_integrate(void *d_volume, const int32_t res[3], const float dim[3], in
     if (e == hipSuccess) e = hipMemsetAsync(d_count, 0, sizeof(unsigned), s);
     if (e == hipSuccess)
         e = launch_integrate(static_cast<short2 *>(d_volume), res, dim, z0, z1, d_depth, w, h, d_inv, Km, mu,
-                             maxweight, nullptr, reinterpret_cast<unsigned *>(scratch + 512), d_count, s);
+                             maxweight, nullptr, reinterpret_cast<unsigned *>(scratch + 512), d_count, nullptr, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     (void)hipFree(scratch);
     KFH_HIP(e);
@@ -804,7 +845,7 @@ int kfh_k_raycast(void *d_vertex4, void *d_normal4, int w, int h, const void *d_
     if (e == hipSuccess)
         e = launch_raycast(static_cast<float4 *>(d_vertex4), static_cast<float4 *>(d_normal4), nullptr, nullptr, w, h,
                            static_cast<const short2 *>(d_volume), res, dim, 0, res[2], d_view, near_plane,
-                           far_plane, step, largestep, scratch + 512, d_count, s);
+                           far_plane, step, largestep, scratch + 512, d_count, nullptr, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     (void)hipFree(scratch);
     KFH_HIP(e);

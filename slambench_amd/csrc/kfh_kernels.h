@@ -131,6 +131,7 @@ hipError_t launch_track_reduce(Ctrl *scratch_ctrl, float *partials, float *sums,
 hipError_t launch_sum_partials(float *sums, const float *partials, int nrows, hipStream_t s);
 hipError_t launch_update_pose(float *pose16, double *x6, int *converged, const float *sums, float thr,
                               hipStream_t s);
+hipError_t launch_update_pose_chain(float *pose16, const float *sums, float thr, int n, hipStream_t s);
 hipError_t launch_pose_derive(Ctrl *ctrl, const float k[4], int set_raycast_pose, hipStream_t s);
 // Two launches: a plan launch lists the 64 x 4 x zchunk boxes that can touch the camera frustum, the work launch
 // fuses the depth map into those.  `boxes` holds integrate_box_list_bytes() bytes and *box_count must be zero
@@ -138,14 +139,20 @@ hipError_t launch_pose_derive(Ctrl *ctrl, const float k[4], int set_raycast_pose
 size_t integrate_box_list_bytes(const int res[3], int z1);
 hipError_t launch_integrate(short2 *vol, const int res[3], const float dim[3], int z0, int z1,
                             const float *depth, int w, int h, const Mat4 *inv_track, Mat4 K, float mu,
-                            float maxweight, const int *gate, unsigned *boxes, unsigned *box_count, hipStream_t s);
+                            float maxweight, const int *gate, unsigned *boxes, unsigned *box_count,
+                            unsigned char *bricks, hipStream_t s);
+// One byte per 8^3-voxel brick ("nothing a coarse raycast step could notice in here"): integrate clears marks,
+// raycast skips marked bricks.  Optional (null) in both launches; whole volumes only.
+inline size_t brick_mark_bytes(const int res[3]) {
+    return (size_t)((res[0] + 7) / 8) * ((res[1] + 7) / 8) * ((res[2] + 7) / 8);
+}
 // Two launches: per-pixel march, then the rays it left unfinished.  `tasks` holds raycast_task_bytes(w, h)
 // bytes and *task_count must be zero when the first launch starts.
 size_t raycast_task_bytes(int w, int h);
 hipError_t launch_raycast(float4 *vertex, float4 *normal, float *ray_t, float4 *ref_tn, int w, int h,
                           const short2 *vol, const int res[3], const float dim[3], int z0, int z1, const Mat4 *view,
                           float near_plane, float far_plane, float step, float largestep, void *tasks,
-                          unsigned *task_count, hipStream_t s);
+                          unsigned *task_count, const unsigned char *bricks, hipStream_t s);
 hipError_t launch_composite(float4 *vertex, float4 *normal, float *ray_t, float4 *ref_tn, const float *t_parts,
                             const float4 *v_parts, const float4 *n_parts, int n_parts_count, int npix,
                             hipStream_t s);

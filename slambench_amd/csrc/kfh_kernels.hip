@@ -1283,6 +1283,32 @@ hipError_t launch_update_pose(float *pose16, double *x6, int *converged, const f
     return hipGetLastError();
 }
 
+// Diagnostic: n dependent pose updates by one wavefront (each update perturbs the sums of the next), to time
+// the solve + exponential + pose product chain without launch effects.
+__global__ void k_update_pose_chain(float *pose16, const float *sums, float thr, int n) {
+    __shared__ float s[32];
+    Mat4 pose;
+    for (int i = 0; i < 16; ++i) pose.m[i] = pose16[i];
+    if (threadIdx.x < 32) s[threadIdx.x] = sums[threadIdx.x];
+    __syncthreads();
+    double x[6];
+    int path = 0;
+    for (int it = 0; it < n; ++it) {
+        update_pose_wave(pose, s, thr, x, &path);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        if (threadIdx.x == 1) s[1] = s[1] * (1.0f + 1e-7f * (float)(x[0] > 0 ? 1 : -1));
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    if (threadIdx.x == 0)
+        for (int i = 0; i < 16; ++i) pose16[i] = pose.m[i];
+}
+
+hipError_t launch_update_pose_chain(float *pose16, const float *sums, float thr, int n, hipStream_t s) {
+    hipLaunchKernelGGL(k_update_pose_chain, dim3(1), dim3(64), 0, s, pose16, sums, thr, n);
+    return hipGetLastError();
+}
+
 struct K4 { float k[4]; };
 __global__ void k_pose_derive(Ctrl *c, K4 k, int set_raycast_pose) {
     if (threadIdx.x == 0) derive_matrices(c, k.k, set_raycast_pose != 0);
@@ -1303,6 +1329,10 @@ hipError_t launch_pose_derive(Ctrl *ctrl, const float k[4], int set_raycast_pose
 // Algorithmic bytes (convention): 8 B per voxel (4 read + 4 written) x voxels of the slab.
 // =====================================================================================================
 constexpr int INTEGRATE_UNROLL = 8;
+// smallest raw tsdf for which a trilinear sample is certainly >= 0.8:  26300 * 0.0000305194 = 0.8027, and
+// the interpolation of values >= m stays above m * (1 - 1e-6)
+constexpr int RAY_COARSE_SAFE = 26300;
+
 
 // Correctly rounded float division with the denominator's reciprocal shared between several numerators.
 // This is the instruction sequence of the compiler's own IEEE division (reciprocal estimate, one Newton
@@ -1323,6 +1353,8 @@ struct IntegrateArgs {
     int gx, gy, gz;             // boxes of 64 x 4 x zchunk voxels
     unsigned *boxes;            // list of boxes that may touch the camera frustum (packed bx | by << 8 | bz << 20)
     unsigned *box_count;
+    unsigned char *bricks;      // per 8^3 brick: 1 while no voxel of the brick (plus one voxel past it) went
+    int bgx, bgy;               //   below RAY_COARSE_SAFE since the last reset; may be null
     unsigned long long *dbg;
 };
 
@@ -1505,6 +1537,18 @@ __global__ __launch_bounds__(256) void k_integrate(IntegrateArgs a) {
                         col[(size_t)(zb + u - a.z0) * plane] = out;
                         if (a.dbg) ++dbg_written;
                     }
+                    // The voxel drops below the level that lets a coarse raycast step pass unseen: every brick
+                    // whose samples can read it (its own, and the previous one along each axis where the voxel
+                    // is the first of its brick) loses its "nothing here" mark.  Marks are only ever cleared.
+                    if (a.bricks && rawk[u].x >= RAY_COARSE_SAFE && out.x < RAY_COARSE_SAFE) {
+                        const int z = zb + u;
+                        const int ex = ((x & 7) == 0 && x > 0) ? 1 : 0, ey = ((y & 7) == 0 && y > 0) ? 1 : 0;
+                        const int ez = ((z & 7) == 0 && z > 0) ? 1 : 0;
+                        for (int iz = 0; iz <= ez; ++iz)
+                            for (int iy = 0; iy <= ey; ++iy)
+                                for (int ix = 0; ix <= ex; ++ix)
+                                    a.bricks[((x >> 3) - ix) + a.bgx * (((y >> 3) - iy) + a.bgy * ((z >> 3) - iz))] = 0;
+                    }
                 }
             }
         }
@@ -1532,7 +1576,8 @@ size_t integrate_box_list_bytes(const int res[3], int z1) {
 
 hipError_t launch_integrate(short2 *vol, const int res[3], const float dim[3], int z0, int z1,
                             const float *depth, int w, int h, const Mat4 *inv_track, Mat4 K, float mu,
-                            float maxweight, const int *gate, unsigned *boxes, unsigned *box_count, hipStream_t s) {
+                            float maxweight, const int *gate, unsigned *boxes, unsigned *box_count,
+                            unsigned char *bricks, hipStream_t s) {
     // Short z chunks: boxes that miss the camera frustum never reach the work launch, the others replay the
     // column prefix (a few packed adds per step) and then march only zchunk steps, so no wavefront runs long.
     IntegrateArgs a;
@@ -1545,6 +1590,7 @@ hipError_t launch_integrate(short2 *vol, const int res[3], const float dim[3], i
     a.zchunk = z1 <= 512 ? 32 : 64;
     a.gx = (res[0] + 63) / 64; a.gy = (res[1] + 3) / 4; a.gz = (z1 + a.zchunk - 1) / a.zchunk;
     a.boxes = boxes; a.box_count = box_count;
+    a.bricks = bricks; a.bgx = (res[0] + 7) / 8; a.bgy = (res[1] + 7) / 8;
     a.dbg = g_integrate_debug;
     if (a.gx > 256 || a.gy > 4096 || a.gz > 4096) return hipErrorInvalidValue;   // packed box id
     const int nbox = a.gx * a.gy * a.gz;
@@ -1577,9 +1623,6 @@ constexpr int RAY_BATCH = 4;        // steps one lane keeps in flight for its ow
 constexpr int RAY_MAX_ROUNDS = 10;  // first pass: at most 40 samples per ray (the median ray needs about 32)
 constexpr int RAY_FEW = 8;          // first pass ends for a wavefront with at most this many live rays
 constexpr int RAY_TAIL_BLOCKS = 1024;
-// smallest raw tsdf for which a trilinear sample is certainly >= 0.8:  26300 * 0.0000305194 = 0.8027, and
-// the interpolation of values >= m stays above m * (1 - 1e-6)
-constexpr int RAY_COARSE_SAFE = 26300;
 
 // value of `v` in lane `src`; src is the same for the whole wavefront
 __device__ inline float bcast_lane(float v, int src) {
@@ -1589,7 +1632,7 @@ __device__ inline float bcast_lane(float v, int src) {
 // Two x-adjacent voxels fetched with one 8-byte load (the volume is only 4-byte aligned at odd x).
 // The empty asm makes the whole 64-bit value live, so the load is not narrowed into two 2-byte loads.
 typedef unsigned long long u64_align4 __attribute__((aligned(4)));
-template <bool POW2>
+template <bool POW2, bool OFF32>
 struct VolDev {
     const short2 *data;
     int sx, sy, sz;
@@ -1598,20 +1641,42 @@ struct VolDev {
     // size / dim; used when POW2 (sizes and dims are powers of two), where pos * size / dim == pos * (size / dim)
     // bit for bit because both scalings are exact
     float scx, scy, scz;
+    // per 8^3 brick: non-zero while all its voxels (plus one past it per axis) are >= RAY_COARSE_SAFE; may be null
+    const unsigned char *bricks;
+    int bgx, bgy;
+    // POW2: log2 of sx, of sx * sy, of bgx and of bgx * bgy (index arithmetic by shifts: a 32-bit integer
+    // multiply issues at a quarter of the rate of a shift)
+    int lsx, lsxy, lbgx, lbgxy;
+    // OFF32: the volume is smaller than 4 GiB, so byte offsets fit 32 bits and loads use base + 32-bit offset
+    // addressing instead of a 64-bit address per lane
+
+    // index of the brick whose mark covers every tap of a sample at pos: the taps lie in [c, c + 1] per axis,
+    // c = max(floor(scaled position), 0)
+    __device__ inline unsigned brick_of(f3 pos) const {
+        const f3 sp = to_voxel(pos);
+        const int cx = min(max((int)floorf(sp.x), 0), sx - 1) >> 3;
+        const int cy = min(max((int)floorf(sp.y), 0), sy - 1) >> 3;
+        const int cz = min(max((int)floorf(sp.z), 0), sz - 1) >> 3;
+        if (POW2) return (unsigned)cx + ((unsigned)cy << lbgx) + ((unsigned)cz << lbgxy);
+        return (unsigned)cx + (unsigned)bgx * ((unsigned)cy + (unsigned)bgy * (unsigned)cz);
+    }
 
     __device__ inline f3 to_voxel(f3 pos) const {
         if (POW2) return mk3(pos.x * scx - 0.5f, pos.y * scy - 0.5f, pos.z * scz - 0.5f);
         return mk3((pos.x * (float)sx / dx) - 0.5f, (pos.y * (float)sy / dy) - 0.5f,
                    (pos.z * (float)sz / dz) - 0.5f);
     }
-    __device__ inline unsigned row(int y) const { return (unsigned)y * (unsigned)sx; }
+    __device__ inline unsigned row(int y) const { return POW2 ? (unsigned)y << lsx : (unsigned)y * (unsigned)sx; }
     __device__ inline unsigned plane(int z) const {
         z = min(max(z, zs0), zs1 - 1) - zs0;
-        return (unsigned)z * (unsigned)(sx * sy);
+        return POW2 ? (unsigned)z << lsxy : (unsigned)z * (unsigned)(sx * sy);
     }
-    __device__ inline float vs(int x, int y, int z) const {
-        return (float)data[(unsigned)x + row(y) + plane(z)].x;
+    // address of voxel number o
+    __device__ inline const short2 *at(unsigned o) const {
+        if (OFF32) return reinterpret_cast<const short2 *>(reinterpret_cast<const char *>(data) + (o << 2));
+        return data + o;
     }
+    __device__ inline float vs(int x, int y, int z) const { return (float)at((unsigned)x + row(y) + plane(z))->x; }
     // Trilinear sample of the raw tsdf shorts in three steps, so that a caller can put the fetches of
     // several samples in flight before it consumes any of them.  lx and ux are either equal or adjacent,
     // so each of the four (y, z) rows needs one 8-byte fetch at x0 = min(lx, sx - 2).
@@ -1642,10 +1707,10 @@ struct VolDev {
     }
     __device__ inline TapData fetch(const Tap &t) const {
         TapData d;
-        d.r00 = *reinterpret_cast<const u64_align4 *>(data + t.o00);
-        d.r10 = *reinterpret_cast<const u64_align4 *>(data + t.o10);
-        d.r01 = *reinterpret_cast<const u64_align4 *>(data + t.o01);
-        d.r11 = *reinterpret_cast<const u64_align4 *>(data + t.o11);
+        d.r00 = *reinterpret_cast<const u64_align4 *>(at(t.o00));
+        d.r10 = *reinterpret_cast<const u64_align4 *>(at(t.o10));
+        d.r01 = *reinterpret_cast<const u64_align4 *>(at(t.o01));
+        d.r11 = *reinterpret_cast<const u64_align4 *>(at(t.o11));
         return d;
     }
     __device__ static inline float tap_first(unsigned long long r) { return (float)(short)(r & 0xFFFFull); }
@@ -1726,8 +1791,8 @@ struct VolDev {
 };
 
 // Ray through pixel (x, y) and its parameter range inside the (slab of the) volume and [near, far].
-template <bool POW2>
-__device__ inline void ray_setup(const VolDev<POW2> &vol, const Mat4 &view, int x, int y, float zc0, float zc1,
+template <bool POW2, bool OFF32>
+__device__ inline void ray_setup(const VolDev<POW2, OFF32> &vol, const Mat4 &view, int x, int y, float zc0, float zc1,
                                  float near_plane, float far_plane, f3 &direction, float &tnear, float &tfar) {
     const f3 origin = mk3(view.m[3], view.m[7], view.m[11]);
     direction = rotate(view, mk3((float)x, (float)y, 1.f));
@@ -1747,8 +1812,8 @@ __device__ inline void ray_setup(const VolDev<POW2> &vol, const Mat4 &view, int 
 // End of a ray: `hit` says the march stopped at a negative sample f_tt at parameter t, reached with step
 // `stepsize` from the sample at t_prev.  Interpolates the zero crossing, evaluates the normal and writes
 // the pixel of every output map.
-template <bool POW2>
-__device__ inline void finish_ray(const VolDev<POW2> &vol, f3 origin, f3 direction, bool hit, float t, float t_prev,
+template <bool POW2, bool OFF32>
+__device__ inline void finish_ray(const VolDev<POW2, OFF32> &vol, f3 origin, f3 direction, bool hit, float t, float t_prev,
                                   float stepsize, float f_tt, int o, float4 *__restrict__ vertex,
                                   float4 *__restrict__ normal, float *__restrict__ ray_t,
                                   float4 *__restrict__ ref_tn) {
@@ -1793,10 +1858,10 @@ struct RayTask {
 // samples fetched together (their positions only depend on the current step size; a step-size change
 // discards the rest of the batch).  A wavefront stops after RAY_MAX_ROUNDS batches, or when few of its
 // rays are still alive, and appends those rays to the task list of the second pass.
-template <bool POW2>
+template <bool POW2, bool OFF32>
 __global__ __launch_bounds__(256, 5) void k_raycast_march(float4 *__restrict__ vertex, float4 *__restrict__ normal,
                                                        float *__restrict__ ray_t, float4 *__restrict__ ref_tn,
-                                                       int w, int h, VolDev<POW2> vol, float zc0, float zc1,
+                                                       int w, int h, VolDev<POW2, OFF32> vol, float zc0, float zc1,
                                                        const Mat4 *__restrict__ view_p, float near_plane,
                                                        float far_plane, float step, float largestep,
                                                        RayTask *__restrict__ tasks, unsigned *task_count,
@@ -1818,13 +1883,19 @@ __global__ __launch_bounds__(256, 5) void k_raycast_march(float4 *__restrict__ v
     float t = tnear, t_prev = tnear, f_tt = 0.f;
     bool fine = false, hit = false, marching = false;
     if (inside && tnear < tfar) {
-        const auto tap = vol.prep(origin + direction * t);
-        const auto raw = vol.fetch(tap);
         // already inside the surface: nothing to render
-        marching = VolDev<POW2>::min_tsdf(raw) > 0 ? true : vol.combine(tap, raw) > 0;
+        const f3 p0 = origin + direction * t;
+        if (vol.bricks && vol.bricks[vol.brick_of(p0)]) {
+            marching = true;
+        } else {
+            const auto tap = vol.prep(p0);
+            const auto raw = vol.fetch(tap);
+            marching = VolDev<POW2, OFF32>::min_tsdf(raw) > 0 ? true : vol.combine(tap, raw) > 0;
+        }
     }
 
     int rounds = 0;
+    unsigned dbg_samples = 0, dbg_skipped = 0;
     while (true) {
         const unsigned long long alive = __ballot(marching);
         if (alive == 0 || __popcll(alive) <= RAY_FEW || rounds == max_rounds) break;
@@ -1836,46 +1907,77 @@ __global__ __launch_bounds__(256, 5) void k_raycast_march(float4 *__restrict__ v
             tk[0] = t;
 #pragma unroll
             for (int k = 1; k < RAY_BATCH; ++k) tk[k] = tk[k - 1] + stepsize;
-            typename VolDev<POW2>::TapData raw[RAY_BATCH];
+            typename VolDev<POW2, OFF32>::TapData raw[RAY_BATCH];
 #pragma unroll
             for (int k = 0; k < RAY_BATCH; ++k) {
                 const float ts = tk[k] < tfar ? tk[k] : t;      // never sample past the far bound
                 pos[k] = origin + direction * ts;
             }
+            // With the coarse step a sample in a brick marked "all voxels >= RAY_COARSE_SAFE" cannot be an event:
+            // one byte per sample (the marks of a 512^3 volume fit the caches) instead of four 8-byte gathers.
+            bool skip[RAY_BATCH];
 #pragma unroll
-            for (int k = 0; k < RAY_BATCH; ++k) raw[k] = vol.fetch(vol.prep(pos[k]));
-            bool need[RAY_BATCH], any_need = false;
+            for (int k = 0; k < RAY_BATCH; ++k) skip[k] = false;
+            if (vol.bricks && !fine) {
+                unsigned char mark[RAY_BATCH];
 #pragma unroll
-            for (int k = 0; k < RAY_BATCH; ++k) {
-                const int mn = VolDev<POW2>::min_tsdf(raw[k]);
-                need[k] = fine ? mn < 0 : mn < RAY_COARSE_SAFE;
-                any_need = any_need || need[k];
-                fk[k] = 1.0f;                                   // stands for "no event possible"
+                for (int k = 0; k < RAY_BATCH; ++k) mark[k] = vol.bricks[vol.brick_of(pos[k])];
+#pragma unroll
+                for (int k = 0; k < RAY_BATCH; ++k) skip[k] = mark[k] != 0;
             }
-            if (any_need) {
+#pragma unroll
+            for (int k = 0; k < RAY_BATCH; ++k) fk[k] = 1.0f;       // stands for "no event possible"
+            if (!(skip[0] && skip[1] && skip[2] && skip[3])) {
+                static_assert(RAY_BATCH == 4, "the skip test above spells out four samples");
 #pragma unroll
                 for (int k = 0; k < RAY_BATCH; ++k) {
-                    if (need[k]) {
-                        f3 p = pos[k];
-                        asm volatile("" : "+v"(p.x), "+v"(p.y), "+v"(p.z));   // recompute the fractions here
-                        fk[k] = vol.combine(vol.prep(p), raw[k]);
+                    raw[k].r00 = raw[k].r10 = raw[k].r01 = raw[k].r11 = 0ull;
+                    if (!skip[k]) raw[k] = vol.fetch(vol.prep(pos[k]));
+                }
+                bool need[RAY_BATCH], any_need = false;
+#pragma unroll
+                for (int k = 0; k < RAY_BATCH; ++k) {
+                    const int mn = VolDev<POW2, OFF32>::min_tsdf(raw[k]);
+                    need[k] = !skip[k] && (fine ? mn < 0 : mn < RAY_COARSE_SAFE);
+                    any_need = any_need || need[k];
+                }
+                if (any_need) {
+#pragma unroll
+                    for (int k = 0; k < RAY_BATCH; ++k) {
+                        if (need[k]) {
+                            f3 p = pos[k];
+                            asm volatile("" : "+v"(p.x), "+v"(p.y), "+v"(p.z));   // recompute the fractions here
+                            fk[k] = vol.combine(vol.prep(p), raw[k]);
+                        }
                     }
                 }
             }
-            bool restart = false;
+            if (dbg) {
 #pragma unroll
-            for (int k = 0; k < RAY_BATCH; ++k) {
-                if (!marching || restart) continue;
-                if (!(tk[k] < tfar)) { marching = false; continue; }           // left the volume: no hit
-                if (fk[k] < 0) { t = tk[k]; f_tt = fk[k]; hit = true; marching = false; continue; }
-                t_prev = tk[k];
-                if (fk[k] < 0.8f && !fine) {
-                    fine = true;
-                    t = tk[k] + step;
-                    restart = true;
+                for (int k = 0; k < RAY_BATCH; ++k) {
+                    dbg_samples += 1;
+                    dbg_skipped += skip[k] ? 1 : 0;
                 }
             }
-            if (marching && !restart) t = tk[RAY_BATCH - 1] + stepsize;
+            // The samples are consumed in order; written with selects instead of branches (a lane that has met
+            // its event stops being `active`), so the four steps cost a few compares each.
+            bool active = true;
+#pragma unroll
+            for (int k = 0; k < RAY_BATCH; ++k) {
+                const bool in = tk[k] < tfar;
+                const bool neg = active && in && fk[k] < 0;                  // zero crossing
+                const bool cont = active && in && !(fk[k] < 0);
+                const bool ends = active && !in;                             // left the volume: no hit
+                const bool sw = cont && !fine && fk[k] < 0.8f;               // switch to the fine step
+                t = neg ? tk[k] : (sw ? tk[k] + step : t);
+                f_tt = neg ? fk[k] : f_tt;
+                hit = hit || neg;
+                t_prev = cont ? tk[k] : t_prev;
+                fine = fine || sw;
+                marching = marching && !(ends || neg);
+                active = cont && !sw;
+            }
+            if (active) t = tk[RAY_BATCH - 1] + stepsize;
         }
     }
 
@@ -1905,6 +2007,15 @@ __global__ __launch_bounds__(256, 5) void k_raycast_march(float4 *__restrict__ v
         d[2] = rounds;
         d[3] = __popcll(left);
     }
+    if (dbg) {      // lane sums of samples taken / skipped by brick marks, packed into the record's upper halves
+        unsigned long long a = dbg_samples, b = dbg_skipped;
+        for (int m = 32; m >= 1; m >>= 1) { a += __shfl_xor(a, m, 64); b += __shfl_xor(b, m, 64); }
+        if (lane == 0) {
+            unsigned long long *d = dbg + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave) * 4;
+            d[2] |= a << 32;
+            d[3] |= b << 32;
+        }
+    }
 }
 
 // Second pass: RAY_TAIL_LANES lanes share one unfinished ray; lane k of the group evaluates step k of the
@@ -1912,10 +2023,10 @@ __global__ __launch_bounds__(256, 5) void k_raycast_march(float4 *__restrict__ v
 // them), and the first lane in step order that meets a loop exit or a step-size change decides.  Long
 // rays (grazing a surface with the fine step) thus take a sixteenth of the dependent round trips, and
 // the task list spreads them over the whole device instead of the few tiles they come from.
-template <bool POW2, int RAY_TAIL_LANES>
+template <bool POW2, bool OFF32, int RAY_TAIL_LANES>
 __global__ __launch_bounds__(256) void k_raycast_tail(float4 *__restrict__ vertex, float4 *__restrict__ normal,
                                                       float *__restrict__ ray_t, float4 *__restrict__ ref_tn, int w,
-                                                      int h, VolDev<POW2> vol, float zc0, float zc1,
+                                                      int h, VolDev<POW2, OFF32> vol, float zc0, float zc1,
                                                       const Mat4 *__restrict__ view_p, float near_plane,
                                                       float far_plane, float step, float largestep,
                                                       const RayTask *__restrict__ tasks,
@@ -1948,7 +2059,7 @@ __global__ __launch_bounds__(256) void k_raycast_tail(float4 *__restrict__ verte
             const bool valid = tk < tfar;
             const auto tap = vol.prep(origin + direction * (valid ? tk : bt));
             const auto raw = vol.fetch(tap);
-            const int mn = VolDev<POW2>::min_tsdf(raw);
+            const int mn = VolDev<POW2, OFF32>::min_tsdf(raw);
             const bool need = go && valid && (fine ? mn < 0 : mn < RAY_COARSE_SAFE);
             float f = 1.0f;
             if (need) f = vol.combine(tap, raw);
@@ -1991,13 +2102,21 @@ __global__ __launch_bounds__(256) void k_raycast_tail(float4 *__restrict__ verte
 static unsigned long long *g_raycast_debug = nullptr;   // diagnostics buffer, [blocks][4 waves][4]
 void set_raycast_debug(unsigned long long *d_buffer) { g_raycast_debug = d_buffer; }
 
-template <bool POW2>
+template <bool POW2, bool OFF32>
 static hipError_t launch_raycast_t(float4 *vertex, float4 *normal, float *ray_t, float4 *ref_tn, int w, int h,
                                    const short2 *vol, const int res[3], const float dim[3], int z0, int z1,
                                    const Mat4 *view, float near_plane, float far_plane, float step, float largestep,
-                                   void *tasks, unsigned *task_count, hipStream_t s) {
-    VolDev<POW2> v;
+                                   void *tasks, unsigned *task_count, const unsigned char *bricks, hipStream_t s) {
+    VolDev<POW2, OFF32> v;
     v.data = vol;
+    v.bricks = bricks;
+    v.bgx = (res[0] + 7) / 8;
+    v.bgy = (res[1] + 7) / 8;
+    auto ilog2 = [](int n) { int l = 0; while ((1 << l) < n) ++l; return l; };
+    v.lsx = ilog2(res[0]);
+    v.lsxy = v.lsx + ilog2(res[1]);
+    v.lbgx = ilog2(v.bgx);
+    v.lbgxy = v.lbgx + ilog2(v.bgy);
     v.sx = res[0]; v.sy = res[1]; v.sz = res[2];
     v.dx = dim[0]; v.dy = dim[1]; v.dz = dim[2];
     v.scx = (float)res[0] / dim[0]; v.scy = (float)res[1] / dim[1]; v.scz = (float)res[2] / dim[2];
@@ -2017,18 +2136,18 @@ static hipError_t launch_raycast_t(float4 *vertex, float4 *normal, float *ray_t,
     // tuning knobs for experiments (defaults: RAY_MAX_ROUNDS, 32 lanes per unfinished ray)
     static const int max_rounds = std::getenv("KFH_RAY_ROUNDS") ? std::atoi(std::getenv("KFH_RAY_ROUNDS")) : RAY_MAX_ROUNDS;
     static const int tail_lanes = std::getenv("KFH_RAY_TAIL_LANES") ? std::atoi(std::getenv("KFH_RAY_TAIL_LANES")) : 32;
-    hipLaunchKernelGGL(k_raycast_march<POW2>, grid, dim3(256), 0, s, vertex, normal, ray_t, ref_tn, w, h, v, zc0, zc1,
+    hipLaunchKernelGGL((k_raycast_march<POW2, OFF32>), grid, dim3(256), 0, s, vertex, normal, ray_t, ref_tn, w, h, v, zc0, zc1,
                        view, near_plane, far_plane, step, largestep, static_cast<RayTask *>(tasks), task_count,
                        max_rounds, g_raycast_debug);
     const RayTask *ct = static_cast<const RayTask *>(tasks);
     if (tail_lanes == 64)
-        hipLaunchKernelGGL((k_raycast_tail<POW2, 64>), dim3(RAY_TAIL_BLOCKS * 2), dim3(256), 0, s, vertex, normal, ray_t,
+        hipLaunchKernelGGL((k_raycast_tail<POW2, OFF32, 64>), dim3(RAY_TAIL_BLOCKS * 2), dim3(256), 0, s, vertex, normal, ray_t,
                            ref_tn, w, h, v, zc0, zc1, view, near_plane, far_plane, step, largestep, ct, task_count);
     else if (tail_lanes == 32)
-        hipLaunchKernelGGL((k_raycast_tail<POW2, 32>), dim3(RAY_TAIL_BLOCKS), dim3(256), 0, s, vertex, normal, ray_t,
+        hipLaunchKernelGGL((k_raycast_tail<POW2, OFF32, 32>), dim3(RAY_TAIL_BLOCKS), dim3(256), 0, s, vertex, normal, ray_t,
                            ref_tn, w, h, v, zc0, zc1, view, near_plane, far_plane, step, largestep, ct, task_count);
     else
-        hipLaunchKernelGGL((k_raycast_tail<POW2, 16>), dim3(RAY_TAIL_BLOCKS), dim3(256), 0, s, vertex, normal, ray_t,
+        hipLaunchKernelGGL((k_raycast_tail<POW2, OFF32, 16>), dim3(RAY_TAIL_BLOCKS), dim3(256), 0, s, vertex, normal, ray_t,
                            ref_tn, w, h, v, zc0, zc1, view, near_plane, far_plane, step, largestep, ct, task_count);
     return hipGetLastError();
 }
@@ -2038,7 +2157,8 @@ size_t raycast_task_bytes(int w, int h) { return (size_t)w * h * sizeof(RayTask)
 hipError_t launch_raycast(float4 *vertex, float4 *normal, float *ray_t, float4 *ref_tn, int w, int h,
                           const short2 *vol, const int res[3], const float dim[3], int z0, int z1, const Mat4 *view,
                           float near_plane, float far_plane, float step, float largestep, void *tasks,
-                          unsigned *task_count, hipStream_t s) {
+                          unsigned *task_count, const unsigned char *bricks, hipStream_t s) {
+    if (bricks && !(z0 == 0 && z1 == res[2])) return hipErrorInvalidValue;   // marks describe whole volumes only
     bool pow2 = true;
     for (int i = 0; i < 3; ++i) {
         int e = 0;
@@ -2046,10 +2166,13 @@ hipError_t launch_raycast(float4 *vertex, float4 *normal, float *ray_t, float4 *
         const bool res_pow2 = (res[i] & (res[i] - 1)) == 0;
         if (!dim_pow2 || !res_pow2 || res[i] < 2) pow2 = false;
     }
-    return pow2 ? launch_raycast_t<true>(vertex, normal, ray_t, ref_tn, w, h, vol, res, dim, z0, z1, view, near_plane,
-                                         far_plane, step, largestep, tasks, task_count, s)
-                : launch_raycast_t<false>(vertex, normal, ray_t, ref_tn, w, h, vol, res, dim, z0, z1, view, near_plane,
-                                          far_plane, step, largestep, tasks, task_count, s);
+    const int stored = (z0 == 0 && z1 == res[2]) ? res[2] : (z1 + 2 < res[2] ? z1 + 2 : res[2]) - (z0 - 2 > 0 ? z0 - 2 : 0);
+    const bool off32 = (double)res[0] * res[1] * stored * sizeof(short2) <= 4294967296.0 - 16.0;
+#define KFH_RAYCAST_ARGS vertex, normal, ray_t, ref_tn, w, h, vol, res, dim, z0, z1, view, near_plane, far_plane, step, \
+                         largestep, tasks, task_count, bricks, s
+    if (pow2) return off32 ? launch_raycast_t<true, true>(KFH_RAYCAST_ARGS) : launch_raycast_t<true, false>(KFH_RAYCAST_ARGS);
+    return off32 ? launch_raycast_t<false, true>(KFH_RAYCAST_ARGS) : launch_raycast_t<false, false>(KFH_RAYCAST_ARGS);
+#undef KFH_RAYCAST_ARGS
 }
 
 // Per pixel, keep the slab candidate with the smallest positive hit distance.

@@ -147,6 +147,8 @@ class KFusion:
         elif buffer == native.BUF_VOLUME:
             rx, ry, _ = self.cfg.volume_resolution
             out = np.empty((nbytes // (4 * rx * ry), ry, rx, 2), np.int16)
+        elif buffer == native.BUF_BRICK_MARKS:
+            out = np.empty(tuple((r + 7) // 8 for r in reversed(self.cfg.volume_resolution)), np.uint8)
         else:
             raise ValueError("unknown buffer %r" % (buffer,))
         assert out.nbytes == nbytes, (out.nbytes, nbytes)

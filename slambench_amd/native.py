@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libkfusion_hip_core.so")
 
 KFH_OK = 0
 BUF_FLOAT_DEPTH, BUF_SCALED_DEPTH, BUF_INPUT_VERTEX, BUF_INPUT_NORMAL = 0, 1, 2, 3
-BUF_MODEL_VERTEX, BUF_MODEL_NORMAL, BUF_VOLUME, BUF_RAY_T = 4, 5, 6, 7
+BUF_MODEL_VERTEX, BUF_MODEL_NORMAL, BUF_VOLUME, BUF_RAY_T, BUF_BRICK_MARKS = 4, 5, 6, 7, 8
 
 # every symbol include/kfusion_hip.h declares
 EXPORTED_SYMBOLS = (

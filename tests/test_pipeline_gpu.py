@@ -88,6 +88,30 @@ def test_buffers_match_oracle_while_pose_is_initial(torch_cuda):
     kf.close()
 
 
+def test_brick_marks_are_conservative(torch_cuda):
+    """The raycast skips a coarse-step sample when the brick holding its base voxel is marked: the mark must
+    imply that every voxel the sample can read (the brick plus one voxel past it per axis) is at or above
+    26300, the level that keeps the interpolated value above 0.8.  Checked on the volume after a sequence."""
+    cfg = KFusionConfig(compute_size_ratio=4, volume_resolution=(96, 80, 72))
+    depth, gt, ts = synth.make_sequence(24, seed=5, noise=True)
+    kf = KFusion(cfg)
+    for i in range(depth.shape[0]):
+        kf.process_frame(depth[i])
+    vol = kf.download(native.BUF_VOLUME)[..., 0].astype(np.int32)          # [z][y][x]
+    marks = kf.download(native.BUF_BRICK_MARKS)
+    assert marks.shape == (9, 10, 12)
+    assert 0 < int(marks.sum()) < marks.size                                # some cleared, some kept
+    low = vol < 26300
+    Z, Y, X = vol.shape
+    for bz, by, bx in zip(*np.nonzero(marks)):
+        region = low[8 * bz:min(8 * bz + 9, Z), 8 * by:min(8 * by + 9, Y), 8 * bx:min(8 * bx + 9, X)]
+        assert not region.any(), (bx, by, bz)
+    # and the marks are not uselessly pessimistic: a brick far from every low voxel is still marked
+    cleared = marks == 0
+    assert cleared.sum() < 0.8 * marks.size
+    kf.close()
+
+
 def test_tracking_rate_and_filtered_integration(torch_cuda):
     cfg = KFusionConfig(compute_size_ratio=4, volume_resolution=(64, 64, 64), tracking_rate=2, integration_rate=3,
                         integrate_filtered=True, pyramid=(4, 3, 2))

@@ -22,6 +22,10 @@ buf = np.zeros(nb * 16 + 1, np.uint64)
 for rep in range(2):
     native.check(L.kfh_debug_raycast_stats(kf._ctx, buf.ctypes.data_as(C.c_void_p)))
 st = buf[:nb * 16].reshape(nb * 4, 4).astype(np.int64)
+samples, skipped = (st[:, 2] >> 32).sum(), (st[:, 3] >> 32).sum()
+st[:, 2] &= 0xFFFFFFFF
+st[:, 3] &= 0xFFFFFFFF
+print('samples in the first pass: %d (%.1f per ray), skipped by brick marks: %d (%.1f%%)' % (samples, samples / (w * h), skipped, 100.0 * skipped / max(samples, 1)))
 print('rays handed to the second pass:', int(buf[-1]) & 0xFFFFFFFF)
 t0 = st[:, 0].min()
 start = (st[:, 0] - t0) / 100.0
