@@ -254,15 +254,18 @@ struct PartialRows {
     float4 t[MAXPASS];
 };
 
+// Branch-free on purpose: every pass loads a valid row (the index is clamped; the buffer always holds at least
+// one row) so that all passes are requested back to back; stage_partial_rows leaves out the rows past the end.
 template <int NT>
 __device__ inline void load_partial_rows(PartialRows<NT> &pr, const float *__restrict__ partials, int nrows,
                                          int r0 = 0) {
     const int slot = threadIdx.x >> 3, c4 = threadIdx.x & 7;
     const float4 *rows4 = reinterpret_cast<const float4 *>(partials);
+    const int last = max(nrows - 1, 0);
 #pragma unroll
     for (int u = 0; u < PartialRows<NT>::MAXPASS; ++u) {
         const int r = r0 + u * PartialRows<NT>::SLOTS + slot;
-        pr.t[u] = r < nrows ? rows4[r * 8 + c4] : make_float4(0.f, 0.f, 0.f, 0.f);
+        pr.t[u] = rows4[min(r, last) * 8 + c4];
     }
 }
 
@@ -277,7 +280,9 @@ __device__ inline void stage_partial_rows(float *lds, PartialRows<NT> &pr, const
         if (r0 > 0) load_partial_rows<NT>(pr, partials, nrows, r0);
 #pragma unroll
         for (int u = 0; u < MAXPASS; ++u) {
-            acc.x += pr.t[u].x; acc.y += pr.t[u].y; acc.z += pr.t[u].z; acc.w += pr.t[u].w;
+            const bool have = r0 + u * SLOTS + slot < nrows;
+            acc.x += have ? pr.t[u].x : 0.f; acc.y += have ? pr.t[u].y : 0.f;
+            acc.z += have ? pr.t[u].z : 0.f; acc.w += have ? pr.t[u].w : 0.f;
         }
     }
     reinterpret_cast<float4 *>(lds)[slot * 8 + c4] = acc;
@@ -855,9 +860,25 @@ __device__ inline float wave_reduce32(float (&v)[32]) {
 // pixel wavefronts project their pixels with the pose of BEFORE that update and gather the model map there
 // (the update moves few projections across a pixel boundary), and compute the input normals.  With the new
 // pose only pixels whose reference index changed are gathered again.
+// The leading scalar parameters repeat fields of `a`: the dispatcher preloads the first kernel-argument dwords
+// into scalar registers, so the loads that start the critical path (partial rows, control block, depth) can
+// be issued without first waiting for the argument block to arrive from memory.
 template <bool PACKED, int PW, int PPT>
-__global__ __launch_bounds__(64 * (1 + PW)) void k_icp_iteration(IcpIterArgs a) {
+__global__ __launch_bounds__(64 * (1 + PW)) void k_icp_iteration(const float *__restrict__ pre_partials_in,
+                                                                Ctrl *__restrict__ pre_ctrl,
+                                                                const float *__restrict__ pre_in_depth,
+                                                                unsigned long long *pre_stamps,
+                                                                int pre_pending_rows, int pre_seq, int pre_iw,
+                                                                int pre_ih, IcpIterArgs a) {
     constexpr int NT = 64 * (1 + PW);
+    a.partials_in = pre_partials_in;
+    a.ctrl = pre_ctrl;
+    a.in_depth = pre_in_depth;
+    a.stamps = pre_stamps;
+    a.pending_rows = pre_pending_rows;
+    a.seq = pre_seq;
+    a.iw = pre_iw;
+    a.ih = pre_ih;
     __shared__ IcpShared<PW> sh;
     KFH_STAMP(0, 0);
     if (a.stamps != nullptr && threadIdx.x == 0 && blockIdx.x < KFH_STAMP_BLOCKS && a.seq < KFH_STAMP_LAUNCHES)
@@ -1147,11 +1168,16 @@ template <bool PACKED, int PW>
 static bool launch_icp_ppt(const IcpIterArgs &a, int nb, hipStream_t s) {
     const dim3 g(nb), b(64 * (1 + PW));
     switch (a.ppt) {
-        case 1: hipLaunchKernelGGL((k_icp_iteration<PACKED, PW, 1>), g, b, 0, s, a); return true;
-        case 2: hipLaunchKernelGGL((k_icp_iteration<PACKED, PW, 2>), g, b, 0, s, a); return true;
-        case 3: hipLaunchKernelGGL((k_icp_iteration<PACKED, PW, 3>), g, b, 0, s, a); return true;
-        case 5: hipLaunchKernelGGL((k_icp_iteration<PACKED, PW, 5>), g, b, 0, s, a); return true;
-        case 8: hipLaunchKernelGGL((k_icp_iteration<PACKED, PW, 8>), g, b, 0, s, a); return true;
+        case 1: hipLaunchKernelGGL((k_icp_iteration<PACKED, PW, 1>), g, b, 0, s, a.partials_in, a.ctrl, a.in_depth,
+                                    a.stamps, a.pending_rows, a.seq, a.iw, a.ih, a); return true;
+        case 2: hipLaunchKernelGGL((k_icp_iteration<PACKED, PW, 2>), g, b, 0, s, a.partials_in, a.ctrl, a.in_depth,
+                                    a.stamps, a.pending_rows, a.seq, a.iw, a.ih, a); return true;
+        case 3: hipLaunchKernelGGL((k_icp_iteration<PACKED, PW, 3>), g, b, 0, s, a.partials_in, a.ctrl, a.in_depth,
+                                    a.stamps, a.pending_rows, a.seq, a.iw, a.ih, a); return true;
+        case 5: hipLaunchKernelGGL((k_icp_iteration<PACKED, PW, 5>), g, b, 0, s, a.partials_in, a.ctrl, a.in_depth,
+                                    a.stamps, a.pending_rows, a.seq, a.iw, a.ih, a); return true;
+        case 8: hipLaunchKernelGGL((k_icp_iteration<PACKED, PW, 8>), g, b, 0, s, a.partials_in, a.ctrl, a.in_depth,
+                                    a.stamps, a.pending_rows, a.seq, a.iw, a.ih, a); return true;
         default: return false;
     }
 }
