@@ -201,10 +201,11 @@ def main():
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS if integ_ms.size else None,
                 "traffic": traffic,
-                "note": "achieved = 8 B x V^3 per launch (convention: every voxel read and written) / mean "
-                        "HIP-event duration of the integrate launches in the timed region; the kernel skips "
-                        "voxels outside the camera frustum or behind the surface without touching them, so "
-                        "measured traffic is below the algorithmic bytes and frac may exceed 1",
+                "traffic_gbps": (traffic / t_int / 1e9) if (traffic and integ_ms.size) else None,
+                "note": "achieved = 8 B x V^3 per integration (convention: every voxel read and written) / mean "
+                        "HIP-event duration of the integrate launches (plan + work) sampled in the timed region; "
+                        "the kernels skip voxels outside the camera frustum or behind the surface without "
+                        "touching them, so measured traffic is far below the algorithmic bytes and frac exceeds 1",
             },
         }
         if not a.no_cpu_baseline and a.cpu_frames > 0 and world == 1:
