@@ -75,3 +75,45 @@ def run_mini_harness(kfd_path, plugin_args=(), frame_limit=0, library=PLUGIN_PAT
         cmd += ["-fl", str(frame_limit)]
     cmd += list(plugin_args)
     return subprocess.run(cmd, capture_output=True, text=True, timeout=timeout)
+
+
+ACCURACY_COLUMNS = ("ATE_RMSE", "MaxATE", "MeanATE", "OrientationError", "RPE_RMSE")
+
+
+def format_log(properties, timestamps, positions, durations, phase_names, accuracy=None, memory=None):
+    """Text of a SLAMBench-style log: the "Properties:" block, then "Statistics:" with one tab-separated row per
+    frame, numbers in fixed notation with 10 decimals (reference framework/shared/src/ColumnWriter.cpp:143-177
+    for the header and rows; column order of SLAMBenchConfiguration.cpp:444-522: frame number, timestamp,
+    accuracy metrics when ground truth exists, Duration_Frame and one Duration_ column per phase, memory,
+    then the position of the main pose output).
+
+    durations: [n, 1 + len(phase_names)] seconds (frame first); accuracy: list of dicts from
+    metrics.frame_metrics or None; memory: [n, 2] (CPU, GPU bytes) or None."""
+    out = ["Properties:", "=================", ""]
+    for k, v in properties.items():
+        out.append("%s: %s" % (k, v))
+    cols = ["Frame Number", "Timestamp"]
+    if accuracy is not None:
+        cols += list(ACCURACY_COLUMNS)
+    cols += ["Duration_Frame"] + ["Duration_" + p for p in phase_names]
+    if memory is not None:
+        cols += ["CPU_Memory", "GPU_Memory"]
+    cols += ["X", "Y", "Z"]
+    out += ["", "Statistics:", "=================", "", "\t".join(cols)]
+
+    def num(v):
+        v = float(v)
+        if v != v:
+            return "-nan" if np.signbit(v) else "nan"
+        return "%.10f" % v
+
+    for i in range(len(timestamps)):
+        row = [str(i + 1), num(timestamps[i])]
+        if accuracy is not None:
+            row += [num(accuracy[i][c]) for c in ACCURACY_COLUMNS]
+        row += [num(d) for d in durations[i]]
+        if memory is not None:
+            row += [str(int(memory[i][0])), str(int(memory[i][1]))]
+        row += [num(p) for p in positions[i]]
+        out.append("\t".join(row))
+    return "\n".join(out) + "\n"

@@ -171,3 +171,100 @@ def test_mini_harness_exit_codes_without_a_gpu(tmp_path):
         r = harness.run_mini_harness(path, ["-c", "1", "-v", "32"])
         assert r.returncode == 1 and "initialization failed" in r.stderr
         assert "compute-size-ratio: 1" in r.stdout and "volume-resolution: 32,32,32" in r.stdout
+
+
+# ------------------------------------------------------------------ .slam container, RPE, log writer
+def test_slam_file_layout_and_round_trip(tmp_path):
+    """Byte layout of the header as the reference serialises it, then a full round trip."""
+    import struct
+    from slambench_amd import slamfile
+    depth, gt, ts = synth.make_sequence(3, seed=4)
+    path = str(tmp_path / "t.slam")
+    sensors = slamfile.write_depth_sequence(path, depth, ts, (481.2, 480.0, 319.5, 239.5), gt_poses=gt)
+    raw = open(path, "rb").read()
+    assert raw[:5] == b"SLAM\0" and struct.unpack("<II", raw[5:13]) == (1, 4)
+    # first sensor: u8 12 + "GroundTruth\0", u8 22 + "GroundTruthTrajectory\0", u8 index 0, u32 18 + description
+    assert raw[13] == 12 and raw[14:26] == b"GroundTruth\0"
+    assert raw[26] == 22 and raw[27:49] == b"GroundTruthTrajectory\0" and raw[49] == 0
+    assert struct.unpack("<I", raw[50:54]) == (18,) and raw[54:72] == b"GroundTruthSensor\0"
+    assert struct.unpack("<f", raw[72:76]) == (30.0,)                    # rate, then 64-byte pose, 4-byte delay
+    header_gt = 13 + (1 + 12) + (1 + 22) + 1 + (4 + 18) + 4 + 64 + 4
+    assert raw[header_gt] == 5 and raw[header_gt + 1:header_gt + 6] == b"Grey\0"
+    # sizes: Camera block 36 + 60 bytes, Depth block 48 + 20 bytes; frames 9-byte header + payload
+    common = lambda name, typ, desc: (1 + len(name) + 1) + (1 + len(typ) + 1) + 1 + (4 + len(desc) + 1) + 4 + 64 + 4
+    header = 13 + common("GroundTruth", "GroundTruthTrajectory", "GroundTruthSensor") + common("Grey", "Camera", "Grey") + 96 \
+        + common("RGB", "Camera", "RGB") + 96 + common("Depth", "Depth", "Depth") + 68
+    per_step = (9 + 64) + (9 + 640 * 480) + (9 + 3 * 640 * 480) + (9 + 2 * 640 * 480)
+    assert len(raw) == header + 3 * per_step
+    sec, nsec, idx = struct.unpack("<IIB", raw[header:header + 9])
+    assert (sec, nsec, idx) == (0, 0, 0)
+    sensor, d, t, g, gts = slamfile.read_depth_sequence(path)
+    assert sensor.name == "Depth" and (sensor.width, sensor.height) == (640, 480)
+    assert sensor.disparity_params == (np.float32(0.001), 0.0) and sensor.pixel_format == 5     # D_I_16
+    assert np.allclose(np.array(sensor.intrinsics) * [640, 480, 640, 480], (481.2, 480.0, 319.5, 239.5), atol=1e-4)
+    assert np.array_equal(d, depth) and np.allclose(t, ts, atol=1e-9) and np.allclose(gts, ts, atol=1e-9)
+    assert np.allclose(g, gt, atol=1e-6)
+    with open(path, "rb") as f:
+        ss = slamfile.read_slam_header(f)
+        kinds = [s.type for _, s, _ in slamfile.iter_frames(f, ss)]
+    assert kinds[:4] == ["GroundTruthTrajectory", "Camera", "Camera", "Depth"] and len(kinds) == 12
+
+
+def test_slam_reader_refuses_what_it_cannot_size(tmp_path):
+    from slambench_amd import slamfile
+    bad = tmp_path / "bad.slam"
+    bad.write_bytes(b"SLAN\0" + bytes(8))
+    with pytest.raises(ValueError, match="magic"):
+        slamfile.read_slam_header(open(bad, "rb"))
+    imu = tmp_path / "imu.slam"
+    with open(imu, "wb") as f:
+        f.write(b"SLAM\0" + (1).to_bytes(4, "little") + (1).to_bytes(4, "little"))
+        f.write(bytes([4]) + b"IMU\0" + bytes([4]) + b"IMU\0" + bytes([0]) + (1).to_bytes(4, "little") + b"\0" + bytes(72))
+    with pytest.raises(ValueError, match="does not support"):
+        slamfile.read_slam_header(open(imu, "rb"))
+
+
+def test_rpe_definition():
+    """RPE_RMSE of the reference: consecutive estimates, translation of (E_i E_j^-1)(G_i G_j^-1)^-1."""
+    from slambench_amd.metrics import rpe, frame_metrics
+    depth, gt, ts = synth.make_sequence(8, seed=2)
+    assert rpe(gt, gt, ts, ts) < 1e-12                      # a perfect trajectory has no relative error
+    assert rpe(gt[:1], gt, ts[:1], ts) == 0.0               # fewer than two poses: 0 by definition
+    est = gt.copy()
+    est[5:, 0, 3] += 0.01                                   # one 1 cm jump between frames 4 and 5
+    want = np.sqrt(sum(np.linalg.norm(((est[i - 1] @ np.linalg.inv(est[i])) @ np.linalg.inv(gt[i - 1] @ np.linalg.inv(gt[i])))[:3, 3]) ** 2
+                       for i in range(1, 8)) / 7)
+    assert abs(rpe(est, gt, ts, ts) - want) < 1e-12
+    assert abs(want - 0.01 / np.sqrt(7)) < 2e-4             # the jump, seen through the rotation of the pair
+    rows = frame_metrics(est, gt, ts, ts)
+    assert len(rows) == 8 and set(rows[0]) == {"ATE_RMSE", "MaxATE", "MeanATE", "OrientationError", "RPE_RMSE"}
+    assert rows[0]["RPE_RMSE"] == 0.0 and rows[-1]["MaxATE"] >= rows[-1]["MeanATE"] > 0
+
+
+def test_log_writer_matches_the_reference_log_shape():
+    """Same sections, separators and number formatting as the reference's log files (checked against the
+    kept head of violons_libkfusion-cpp_living_room_traj2_loop.log)."""
+    import os
+    ref = open(os.path.join(os.path.dirname(__file__), "golden", "ref_kfusion_cpp_lr_kt2_head.tsv")).read()
+    rprops, rcols, rrows = harness.parse_log(ref)
+    phases = [c[len("Duration_"):] for c in rcols if c.startswith("Duration_") and c != "Duration_Frame"]
+    assert phases == ["Preprocessing", "Tracking", "Integration", "Raycasting", "Render"]
+    n = 5
+    ts = rrows[:n, rcols.index("Timestamp")]
+    pos = rrows[:n, -3:]
+    dur = rrows[:n, rcols.index("Duration_Frame"):rcols.index("Duration_Frame") + 6]
+    text = harness.format_log({"mu": "0.1", "volume-size": "8,8,8"}, ts, pos, dur, phases)
+    props, cols, rows = harness.parse_log(text)
+    assert props == {"mu": "0.1", "volume-size": "8,8,8"}
+    assert cols == ["Frame Number", "Timestamp", "Duration_Frame"] + ["Duration_" + p for p in phases] + ["X", "Y", "Z"]
+    assert np.array_equal(rows[:, 1], ts) and np.array_equal(rows[:, -3:], pos)
+    # a data row of ours and the reference's row agree character for character on the shared columns
+    ref_row = [l for l in ref.splitlines() if l.startswith("5\t")][0].split("\t")
+    our_row = [l for l in text.splitlines() if l.startswith("5\t")][0].split("\t")
+    assert our_row[:2] == ref_row[:2] and our_row[-3:] == ref_row[-3:]
+    assert our_row[2:8] == ref_row[rcols.index("Duration_Frame"):rcols.index("Duration_Frame") + 6]
+    assert "\nStatistics:\n=================\n\nFrame Number\t" in text and text.startswith("Properties:\n=================\n\n")
+    # with ground truth the accuracy columns sit between the timestamp and the durations
+    acc = [{c: 0.5 for c in harness.ACCURACY_COLUMNS}] * n
+    cols2 = harness.parse_log(harness.format_log({}, ts, pos, dur, phases, acc, np.zeros((n, 2))))[1]
+    assert cols2[2:7] == list(harness.ACCURACY_COLUMNS) and cols2[-5:-3] == ["CPU_Memory", "GPU_Memory"]

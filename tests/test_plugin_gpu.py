@@ -51,3 +51,36 @@ def test_frame_limit_and_bad_option(torch_cuda, tmp_path):
     # an invalid configuration makes sb_init_slam_system return false -> the harness exits with 1
     r = harness.run_mini_harness(path, ["-c", "3"])
     assert r.returncode == 1 and "initialization failed" in r.stderr
+
+
+def test_slam_file_input_matches_kfd_input(torch_cuda, tmp_path):
+    """The same stream as a .slam file (ground truth, grey, RGB and depth frames interleaved, as the
+    reference's dataset generators write them) must give the same trajectory as the .kfd container, and the
+    log can be completed with the harness' accuracy columns."""
+    from slambench_amd import slamfile
+    from slambench_amd.metrics import frame_metrics
+    n = 10
+    intr = (481.2, 480.0, 319.5, 239.5)
+    depth, gt, ts = synth.make_sequence(n, seed=3, intrinsics=intr)
+    kfd, slam = str(tmp_path / "s.kfd"), str(tmp_path / "s.slam")
+    harness.write_kfd(kfd, depth, ts, intr, 0.001)
+    slamfile.write_depth_sequence(slam, depth, ts, intr, gt_poses=gt, disparity_scale=0.001)
+    args = ["-c", "4", "-v", "64,64,64"]
+    a = harness.run_mini_harness(kfd, args)
+    b = harness.run_mini_harness(slam, args)
+    assert a.returncode == 0 and b.returncode == 0, (a.stderr, b.stderr)
+    pa, ca, ra = harness.parse_log(a.stdout)
+    pb, cb, rb = harness.parse_log(b.stdout)
+    assert ca == cb and ra.shape == rb.shape == (n, 11)
+    assert np.array_equal(ra[:, -3:], rb[:, -3:])                       # identical positions, bit for bit
+    np.testing.assert_allclose(ra[:, 1], rb[:, 1], atol=1e-8)
+    assert pb["Depth-disparity-params"].startswith("0.001")
+    # complete the log the way the harness would, from the file's own ground truth
+    sensor, d, dts, g, gts = slamfile.read_depth_sequence(slam)
+    est = np.tile(np.eye(4), (n, 1, 1))
+    est[:, :3, 3] = rb[:, -3:]
+    acc = frame_metrics(est, g, dts, gts)
+    text = harness.format_log(pb, rb[:, 1], rb[:, -3:], rb[:, 2:8], [c[9:] for c in cb[3:8]], acc)
+    cols = harness.parse_log(text)[1]
+    assert cols[2:7] == list(harness.ACCURACY_COLUMNS)
+    assert acc[-1]["ATE_RMSE"] < 0.05
