@@ -95,6 +95,13 @@ enum kfh_buffer {
                                   coarse step.  Unsharded contexts only. */
 };
 
+/* image identifiers for kfh_render: the three pictures of the kfusion plugin's sb_update_outputs */
+enum kfh_render_image {
+    KFH_RENDER_DEPTH = 0,      /* renderDepthKernel: raw metres depth as a hue ramp between the near and far plane */
+    KFH_RENDER_TRACK = 1,      /* renderTrackKernel: result code of the last trackKernel execution per pixel     */
+    KFH_RENDER_VOLUME = 2      /* renderVolumeKernel: the TSDF raycast from a pose and shaded with a point light  */
+};
+
 const char *kfh_last_error(void);
 int kfh_version(void);
 int kfh_device_count(int *count);
@@ -133,6 +140,19 @@ int kfh_stream(kfh_context *ctx, void **stream);
 int kfh_set_timing(kfh_context *ctx, int mode);
 int kfh_phase_ms(kfh_context *ctx, float ms[4]);                 /* most recent frame */
 int kfh_phase_ms_frame(kfh_context *ctx, int frame, float ms[4]);
+
+/* ---- GUI images (the FrameValue outputs of sb_update_outputs) ---- */
+/* RGBA8 images of the compute size (kfh_compute_size), alpha 0.  view_pose is only used by
+ * KFH_RENDER_VOLUME: camera-to-world pose to render from, NULL = the current pose (Kfusion::getViewPose);
+ * the march uses the plugin's parameters (near plane 0.4, far plane 2 * 4.0, large step 0.75 * mu, light at
+ * (1, 1, -1), ambient 0.1).  kfh_render copies to host memory and synchronises; kfh_render_device writes
+ * w * h * 4 bytes of device memory asynchronously on the context's stream.  Not available on z-slab contexts
+ * (KFH_RENDER_VOLUME). */
+int kfh_render(kfh_context *ctx, int image, const float view_pose[16], uint8_t *h_rgba, size_t bytes);
+int kfh_render_device(kfh_context *ctx, int image, const float view_pose[16], uint8_t *d_rgba);
+/* KFH_RENDER_TRACK needs the per-pixel result codes, which tracking only stores (one byte per pixel and
+ * executed iteration) after this call with enabled != 0; codes are zero ("unknown" colour) until tracking runs. */
+int kfh_enable_track_render(kfh_context *ctx, int enabled);
 
 /* ---- z-slab sharding across devices (one context per device) ---- */
 /* March only this context's slab; writes hit distance t (0 = miss), vertex and normal of the nearest
@@ -177,6 +197,16 @@ int kfh_k_integrate(void *d_volume, const int32_t res[3], const float dim[3], in
 int kfh_k_raycast(void *d_vertex4, void *d_normal4, int w, int h, const void *d_volume,
                   const int32_t res[3], const float dim[3], const float view[16],
                   float near_plane, float far_plane, float step, float largestep, void *stream);
+
+/* renderDepthKernel */
+int kfh_k_render_depth(uint8_t *d_rgba, const float *d_depth, int w, int h, float near_plane, float far_plane,
+                       void *stream);
+/* renderTrackKernel on TrackData as kfh_k_track_reduce writes it */
+int kfh_k_render_track(uint8_t *d_rgba, const kfh_track_data *d_track, int track_stride, int w, int h, void *stream);
+/* renderVolumeKernel: raycast from `view` (pose * inverse camera matrix) + shading */
+int kfh_k_render_volume(uint8_t *d_rgba, int w, int h, const void *d_volume, const int32_t res[3], const float dim[3],
+                        const float view[16], float near_plane, float far_plane, float step, float largestep,
+                        const float light[3], const float ambient[3], void *stream);
 
 #ifdef __cplusplus
 }

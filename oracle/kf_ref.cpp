@@ -596,6 +596,89 @@ void kfr_raycast(float *vertex3, float *normal3, int w, int h, const int16_t *vo
         }
 }
 
+/* kernels.cpp gs2rgb: hue ramp used by renderDepthKernel (value 0.75, saturation 2/3, in double) */
+static void gs2rgb(double h, uint8_t out[4]) {
+    double r = 0, g = 0, b = 0;
+    const double v = 0.75;
+    if (v > 0) {
+        const double m = 0.25, sv = 0.6667;
+        h *= 6.0;
+        const int sextant = (int)h;
+        const double fract = h - sextant;
+        const double vsf = v * sv * fract;
+        const double mid1 = m + vsf, mid2 = v - vsf;
+        switch (sextant) {
+            case 0: r = v; g = mid1; b = m; break;
+            case 1: r = mid2; g = v; b = m; break;
+            case 2: r = m; g = v; b = mid1; break;
+            case 3: r = m; g = mid2; b = v; break;
+            case 4: r = mid1; g = m; b = v; break;
+            case 5: r = v; g = m; b = mid2; break;
+        }
+    }
+    out[0] = (uint8_t)(r * 255);
+    out[1] = (uint8_t)(g * 255);
+    out[2] = (uint8_t)(b * 255);
+    out[3] = 0;
+}
+
+/* kernels.cpp renderDepthKernel */
+void kfr_render_depth(uint8_t *rgba, const float *depth, int w, int h, float near_plane, float far_plane) {
+    const float range_scale = 1 / (far_plane - near_plane);
+    for (int i = 0; i < w * h; ++i) {
+        uint8_t *o = rgba + 4 * i;
+        if (depth[i] < near_plane) { o[0] = 255; o[1] = 255; o[2] = 255; o[3] = 0; }
+        else if (depth[i] > far_plane) { o[0] = 0; o[1] = 0; o[2] = 0; o[3] = 0; }
+        else {
+            const float d = (depth[i] - near_plane) * range_scale;
+            gs2rgb(d, o);
+        }
+    }
+}
+
+/* kernels.cpp renderTrackKernel */
+void kfr_render_track(uint8_t *rgba, const kfr_track_data *data, int w, int h) {
+    for (int i = 0; i < w * h; ++i) {
+        uint8_t *o = rgba + 4 * i;
+        o[3] = 0;
+        switch (data[i].result) {
+            case 1: o[0] = 128; o[1] = 128; o[2] = 128; break;   /* ok */
+            case -1: o[0] = 0; o[1] = 0; o[2] = 0; break;        /* no input */
+            case -2: o[0] = 255; o[1] = 0; o[2] = 0; break;      /* not in image */
+            case -3: o[0] = 0; o[1] = 255; o[2] = 0; break;      /* no correspondence */
+            case -4: o[0] = 0; o[1] = 0; o[2] = 255; break;      /* too far away */
+            case -5: o[0] = 255; o[1] = 255; o[2] = 0; break;    /* wrong normal */
+            default: o[0] = 255; o[1] = 128; o[2] = 128; break;
+        }
+    }
+}
+
+/* kernels.cpp renderVolumeKernel: second raycast + Phong-style shading with a point light */
+void kfr_render_volume(uint8_t *rgba, int w, int h, const int16_t *vol_, const int32_t res[3], const float dim[3],
+                       const float view_[16], float near_plane, float far_plane, float step, float largestep,
+                       const float light_[3], const float ambient_[3]) {
+    const M4 view = load_m4(view_);
+    VolView vol{vol_, res[0], res[1], res[2], dim[0], dim[1], dim[2]};
+    const f3 light = mk3(light_[0], light_[1], light_[2]), ambient = mk3(ambient_[0], ambient_[1], ambient_[2]);
+#pragma omp parallel for schedule(dynamic, 4)
+    for (int y = 0; y < h; ++y)
+        for (int x = 0; x < w; ++x) {
+            uint8_t *o = rgba + 4 * (x + y * w);
+            o[0] = o[1] = o[2] = o[3] = 0;
+            const f4 hit = raycast_one(vol, x, y, view, near_plane, far_plane, step, largestep);
+            if (hit.w > 0) {
+                const f3 test = mk3(hit.x, hit.y, hit.z);
+                const f3 surf_norm = vol.grad(test);
+                if (length3(surf_norm) > 0) {
+                    const f3 diff = normalize3(light - test);
+                    const float dir = std::fmax(dot3(normalize3(surf_norm), diff), 0.f);
+                    const float c[3] = {dir + ambient.x, dir + ambient.y, dir + ambient.z};
+                    for (int k = 0; k < 3; ++k) o[k] = (uint8_t)(std::fmin(std::fmax(c[k], 0.f), 1.f) * 255);
+                }
+            }
+        }
+}
+
 void kfr_camera_matrix(float K[16], float fx, float fy, float cx, float cy) {
     store_m4(K, camera_matrix(fx, fy, cx, cy));
 }
@@ -757,5 +840,6 @@ const float *kfr_model_vertex(const kfr_context *c) { return c->vertex.data(); }
 const float *kfr_model_normal(const kfr_context *c) { return c->normal.data(); }
 const int16_t *kfr_volume(const kfr_context *c) { return c->volume.data(); }
 const float *kfr_reduction(const kfr_context *c) { return c->reduction; }
+const kfr_track_data *kfr_tracking_result(const kfr_context *c) { return c->tracking_result.data(); }
 
 }  /* extern "C" */

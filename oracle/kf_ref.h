@@ -71,6 +71,12 @@ void kfr_raycast(float *vertex3, float *normal3, int w, int h,
                  const int16_t *vol, const int32_t res[3], const float dim[3],
                  const float view[16], float near_plane, float far_plane,
                  float step, float largestep);
+/* debug images of the use-case (RGBA8, alpha 0): depth colour map, tracking status, shaded second raycast */
+void kfr_render_depth(uint8_t *rgba, const float *depth, int w, int h, float near_plane, float far_plane);
+void kfr_render_track(uint8_t *rgba, const kfr_track_data *data, int w, int h);
+void kfr_render_volume(uint8_t *rgba, int w, int h, const int16_t *vol, const int32_t res[3], const float dim[3],
+                       const float view[16], float near_plane, float far_plane, float step, float largestep,
+                       const float light[3], const float ambient[3]);
 void kfr_camera_matrix(float K[16], float fx, float fy, float cx, float cy);
 void kfr_inverse_camera_matrix(float invK[16], float fx, float fy, float cx, float cy);
 void kfr_mat_inverse(float out[16], const float in[16]);
@@ -97,6 +103,7 @@ const float   *kfr_model_vertex(const kfr_context *c);
 const float   *kfr_model_normal(const kfr_context *c);
 const int16_t *kfr_volume(const kfr_context *c);
 const float   *kfr_reduction(const kfr_context *c);
+const kfr_track_data *kfr_tracking_result(const kfr_context *c);   /* [h][w] of the compute size, last iteration run */
 
 #ifdef __cplusplus
 }

@@ -65,7 +65,7 @@ def lib():
         L.kfr_frame_index.restype = C.c_int
         L.kfr_frame_index.argtypes = [C.c_void_p]
         for name in ("kfr_float_depth", "kfr_model_vertex", "kfr_model_normal", "kfr_volume",
-                     "kfr_reduction"):
+                     "kfr_reduction", "kfr_tracking_result"):
             getattr(L, name).restype = C.c_void_p
             getattr(L, name).argtypes = [C.c_void_p]
         for name in ("kfr_scaled_depth", "kfr_input_vertex", "kfr_input_normal"):
@@ -238,6 +238,37 @@ def raycast(vol, dim, w, h, view, near=0.4, far=4.0, step=None, largestep=0.075)
     return vertex, normal
 
 
+def render_depth(depth, near=0.4, far=4.0):
+    d = _f32(depth)
+    h, w = d.shape
+    out = np.empty((h, w, 4), np.uint8)
+    lib().kfr_render_depth(_p(out), _p(d), C.c_int(w), C.c_int(h), C.c_float(near), C.c_float(far))
+    return out
+
+
+def render_track(track_data):
+    td = np.ascontiguousarray(track_data)
+    assert td.dtype == TRACK_DTYPE
+    h, w = td.shape
+    out = np.empty((h, w, 4), np.uint8)
+    lib().kfr_render_track(_p(out), _p(td), C.c_int(w), C.c_int(h))
+    return out
+
+
+def render_volume(vol, dim, w, h, view, near=0.4, far=8.0, step=None, largestep=0.075,
+                  light=(1.0, 1.0, -1.0), ambient=(0.1, 0.1, 0.1)):
+    assert vol.dtype == np.int16 and vol.flags.c_contiguous
+    res = (C.c_int32 * 3)(vol.shape[2], vol.shape[1], vol.shape[0])
+    dm = (C.c_float * 3)(*[float(v) for v in dim])
+    if step is None:
+        step = np.float32(min(dim)) / np.float32(max(vol.shape[:3]))
+    out = np.empty((h, w, 4), np.uint8)
+    lib().kfr_render_volume(_p(out), C.c_int(w), C.c_int(h), _p(vol), res, dm, _p(_m4(view)),
+                            C.c_float(near), C.c_float(far), C.c_float(float(step)), C.c_float(largestep),
+                            (C.c_float * 3)(*light), (C.c_float * 3)(*ambient))
+    return out
+
+
 # ---------------------------------------------------------------- whole pipeline
 class KFusionRef:
     """Drives kfr_process_frame; mirrors the upstream Kfusion class + sb_process_once order."""
@@ -303,3 +334,6 @@ class KFusionRef:
 
     def reduction(self):
         return self._view(lib().kfr_reduction(self._c), (8, 32), np.float32)[0]
+
+    def tracking_result(self):
+        return self._view(lib().kfr_tracking_result(self._c), (self.h, self.w), TRACK_DTYPE)

@@ -95,6 +95,11 @@ struct kfh_context {
     Ctrl *d_ctrl = nullptr;
     kfh_frame_status *d_status = nullptr;
     unsigned long long *d_stamps = nullptr; // diagnostic ICP time stamps (KFH_ICP_STAMPS=1), [launch][block][slot]
+    // GUI images: allocated when first asked for
+    signed char *d_track_codes = nullptr;  // trackKernel result code per pixel of the compute size
+    float4 *d_render_vertex = nullptr, *d_render_normal = nullptr;   // maps of the volume render's own raycast
+    uchar4 *d_render_rgba = nullptr;
+    char *d_render_state = nullptr;        // [view matrix | unfinished-ray counter at byte 256]
 
     // phase timing: a ring of event sets, one per frame (slot = frame % KFH_TIMING_RING)
     int timing = 0;            // 0 off, 1 all four phases, 2 integration only
@@ -139,7 +144,8 @@ void free_all(kfh_context *c) {
                     c->set_scaled[1][2],
                     c->d_in_vertex[0], c->d_in_vertex[1], c->d_in_vertex[2], c->d_in_normal[0],
                     c->d_in_normal[1], c->d_in_normal[2], c->d_vertex, c->d_normal, c->d_ray_t, c->d_volume, c->d_ref_tn, c->d_ray_tasks, c->d_integrate_boxes, c->d_bricks,
-                    c->d_partials, c->d_ctrl, c->d_status, c->d_stamps};
+                    c->d_partials, c->d_ctrl, c->d_status, c->d_stamps, c->d_track_codes, c->d_render_vertex,
+                    c->d_render_normal, c->d_render_rgba, c->d_render_state};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     if (c->ev) {
@@ -185,6 +191,7 @@ int init_state(kfh_context *c) {
     KFH_HIP(hipMemsetAsync(c->d_ray_t, 0, npix * sizeof(float), c->stream));
     KFH_HIP(hipMemsetAsync(c->d_ref_tn, 0, npix * sizeof(float4), c->stream));
     for (int l = 0; l < 3; ++l) c->in_maps_version[l] = -1;
+    if (c->d_track_codes) KFH_HIP(hipMemsetAsync(c->d_track_codes, 0, npix, c->stream));
     KFH_HIP(hipMemsetAsync(c->d_status, 0, sizeof(kfh_frame_status) * KFH_STATUS_RING, c->stream));
     Ctrl init;
     std::memset(&init, 0, sizeof(init));
@@ -400,6 +407,8 @@ int kfh_track(kfh_context *c) {
         a.normal_threshold = NORMAL_THRESHOLD;
         a.icp_threshold = c->cfg.icp_threshold;
         a.stamps = c->d_stamps;
+        a.result_out = c->d_track_codes;
+        a.result_stride = c->w;
         a.max_blocks = c->compute_units;
         int seq = 0, rows = 0;
         for (int level = 2; level >= 0; --level) {
@@ -484,6 +493,74 @@ int kfh_composite_slabs(kfh_context *c, const float *d_t, const void *d_vertex, 
         KFH_HIP(launch_composite(c->d_vertex, c->d_normal, c->d_ray_t, c->d_ref_tn, d_t, static_cast<const float4 *>(d_vertex),
                                  static_cast<const float4 *>(d_normal), n_parts, c->w * c->h, c->stream));
     }
+    return KFH_OK;
+}
+
+int kfh_enable_track_render(kfh_context *c, int enabled) {
+    KFH_REQUIRE(c != nullptr, "context is NULL");
+    const size_t npix = (size_t)c->w * c->h;
+    if (enabled && !c->d_track_codes) {
+        KFH_HIP(dev_alloc(&c->d_track_codes, npix));
+        KFH_HIP(hipMemsetAsync(c->d_track_codes, 0, npix, c->stream));
+    } else if (!enabled && c->d_track_codes) {
+        KFH_HIP(hipStreamSynchronize(c->stream));   // an iteration launch may still be writing codes
+        KFH_HIP(hipFree(c->d_track_codes));
+        c->d_track_codes = nullptr;
+    }
+    return KFH_OK;
+}
+
+int kfh_render_device(kfh_context *c, int image, const float view_pose[16], uint8_t *d_rgba) {
+    KFH_REQUIRE(c != nullptr && d_rgba != nullptr, "NULL argument");
+    const int npix = c->w * c->h;
+    uchar4 *out = reinterpret_cast<uchar4 *>(d_rgba);
+    KFH_HIP(ensure_pre_done(c));
+    switch (image) {
+        case KFH_RENDER_DEPTH:
+            KFH_HIP(launch_render_depth(out, c->d_float_depth, npix, NEAR_PLANE, FAR_PLANE, c->stream));
+            break;
+        case KFH_RENDER_TRACK:
+            if (!c->d_track_codes)
+                return fail(KFH_ERR_STATE, "tracking keeps no result codes: call kfh_enable_track_render first");
+            KFH_HIP(launch_render_track(out, nullptr, c->d_track_codes, c->w, c->w, c->h, c->stream));
+            break;
+        case KFH_RENDER_VOLUME: {
+            if (c->sharded) return fail(KFH_ERR_STATE, "a z-slab context holds only part of the volume");
+            if (!c->d_render_vertex) KFH_HIP(dev_alloc(&c->d_render_vertex, (size_t)npix));
+            if (!c->d_render_normal) KFH_HIP(dev_alloc(&c->d_render_normal, (size_t)npix));
+            if (!c->d_render_state) KFH_HIP(dev_alloc(&c->d_render_state, (size_t)512));
+            const Mat4 *d_view = &c->d_ctrl->view;             // current pose * inverse camera matrix
+            if (view_pose) {
+                Mat4 pose;
+                std::memcpy(pose.m, view_pose, sizeof(pose.m));
+                Mat4 *dv = reinterpret_cast<Mat4 *>(c->d_render_state);
+                KFH_HIP(launch_view_from_pose(dv, pose, c->k, c->stream));
+                d_view = dv;
+            }
+            unsigned *d_count = reinterpret_cast<unsigned *>(c->d_render_state + 256);
+            KFH_HIP(hipMemsetAsync(d_count, 0, sizeof(unsigned), c->stream));
+            // the frame's own raycast is over (stream order): its task list is free to reuse
+            KFH_HIP(launch_raycast(c->d_render_vertex, c->d_render_normal, nullptr, nullptr, c->w, c->h, c->d_volume,
+                                   c->cfg.vol_res, c->cfg.vol_dim, 0, c->cfg.vol_res[2], d_view, NEAR_PLANE,
+                                   2.0f * FAR_PLANE, raycast_step(c->cfg), 0.75f * c->cfg.mu, c->d_ray_tasks, d_count,
+                                   c->d_bricks, c->stream));
+            const float light[3] = {1.f, 1.f, -1.f}, ambient[3] = {0.1f, 0.1f, 0.1f};
+            KFH_HIP(launch_render_shade(out, c->d_render_vertex, c->d_render_normal, npix, light, ambient, c->stream));
+            break;
+        }
+        default: return fail(KFH_ERR_INVALID_ARG, "unknown image id %d", image);
+    }
+    return KFH_OK;
+}
+
+int kfh_render(kfh_context *c, int image, const float view_pose[16], uint8_t *h_rgba, size_t bytes) {
+    KFH_REQUIRE(c != nullptr && h_rgba != nullptr, "NULL argument");
+    const size_t need = (size_t)c->w * c->h * 4;
+    KFH_REQUIRE(bytes >= need, "image needs %zu bytes, destination holds %zu", need, bytes);
+    if (!c->d_render_rgba) KFH_HIP(dev_alloc(&c->d_render_rgba, (size_t)c->w * c->h));
+    if (int rc = kfh_render_device(c, image, view_pose, reinterpret_cast<uint8_t *>(c->d_render_rgba))) return rc;
+    KFH_HIP(hipMemcpyAsync(h_rgba, c->d_render_rgba, need, hipMemcpyDeviceToHost, c->stream));
+    KFH_HIP(hipStreamSynchronize(c->stream));
     return KFH_OK;
 }
 
@@ -846,6 +923,52 @@ int kfh_k_raycast(void *d_vertex4, void *d_normal4, int w, int h, const void *d_
         e = launch_raycast(static_cast<float4 *>(d_vertex4), static_cast<float4 *>(d_normal4), nullptr, nullptr, w, h,
                            static_cast<const short2 *>(d_volume), res, dim, 0, res[2], d_view, near_plane,
                            far_plane, step, largestep, scratch + 512, d_count, nullptr, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    (void)hipFree(scratch);
+    KFH_HIP(e);
+    return KFH_OK;
+}
+
+int kfh_k_render_depth(uint8_t *d_rgba, const float *d_depth, int w, int h, float near_plane, float far_plane,
+                       void *stream) {
+    KFH_REQUIRE(d_rgba && d_depth, "NULL argument");
+    KFH_REQUIRE(w > 0 && h > 0, "bad sizes");
+    KFH_HIP(launch_render_depth(reinterpret_cast<uchar4 *>(d_rgba), d_depth, w * h, near_plane, far_plane,
+                                static_cast<hipStream_t>(stream)));
+    return KFH_OK;
+}
+
+int kfh_k_render_track(uint8_t *d_rgba, const kfh_track_data *d_track, int track_stride, int w, int h, void *stream) {
+    KFH_REQUIRE(d_rgba && d_track, "NULL argument");
+    KFH_REQUIRE(w > 0 && h > 0 && track_stride >= w, "bad sizes");
+    KFH_HIP(launch_render_track(reinterpret_cast<uchar4 *>(d_rgba), d_track, nullptr, track_stride, w, h,
+                                static_cast<hipStream_t>(stream)));
+    return KFH_OK;
+}
+
+int kfh_k_render_volume(uint8_t *d_rgba, int w, int h, const void *d_volume, const int32_t res[3], const float dim[3],
+                        const float view[16], float near_plane, float far_plane, float step, float largestep,
+                        const float light[3], const float ambient[3], void *stream) {
+    KFH_REQUIRE(d_rgba && d_volume && res && dim && view && light && ambient, "NULL argument");
+    KFH_REQUIRE(w > 0 && h > 0 && res[0] > 0 && res[1] > 0 && res[2] > 0, "bad sizes");
+    KFH_REQUIRE(step > 0.f && largestep > 0.f, "steps must be positive");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    // scratch: [view matrix | task counter | vertex map | normal map | task list]
+    const size_t map_bytes = (size_t)w * h * sizeof(float4);
+    char *scratch = nullptr;
+    KFH_HIP(hipMalloc(reinterpret_cast<void **>(&scratch), 512 + 2 * map_bytes + raycast_task_bytes(w, h)));
+    Mat4 *d_view = reinterpret_cast<Mat4 *>(scratch);
+    unsigned *d_count = reinterpret_cast<unsigned *>(scratch + 256);
+    float4 *d_vertex = reinterpret_cast<float4 *>(scratch + 512);
+    float4 *d_normal = reinterpret_cast<float4 *>(scratch + 512 + map_bytes);
+    hipError_t e = hipMemcpyAsync(d_view, view, sizeof(Mat4), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemsetAsync(d_count, 0, sizeof(unsigned), s);
+    if (e == hipSuccess)
+        e = launch_raycast(d_vertex, d_normal, nullptr, nullptr, w, h, static_cast<const short2 *>(d_volume), res, dim, 0,
+                           res[2], d_view, near_plane, far_plane, step, largestep, scratch + 512 + 2 * map_bytes, d_count,
+                           nullptr, s);
+    if (e == hipSuccess)
+        e = launch_render_shade(reinterpret_cast<uchar4 *>(d_rgba), d_vertex, d_normal, w * h, light, ambient, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     (void)hipFree(scratch);
     KFH_HIP(e);

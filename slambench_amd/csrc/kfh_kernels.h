@@ -92,6 +92,8 @@ struct IcpIterArgs {
     int max_blocks;             // compute units of the device (for that choice)
     kfh_track_data *track_out;  // per-pixel TrackData for parity tests, may be null
     int track_stride;
+    signed char *result_out;    // per-pixel result code of trackKernel (1, -1 .. -5) for the tracking render, may be null
+    int result_stride;
     unsigned long long *stamps; // diagnostic time stamps [launch][block][slot], may be null
 };
 
@@ -160,6 +162,17 @@ hipError_t launch_composite(float4 *vertex, float4 *normal, float *ray_t, float4
 void set_raycast_debug(unsigned long long *d_buffer);
 void set_integrate_debug(unsigned long long *d_buffer);
 hipError_t launch_fill_volume(short2 *vol, size_t nvox, hipStream_t s);
+// The three images of the reference GUI (renderDepthKernel, renderTrackKernel, the shading half of
+// renderVolumeKernel; its raycast half is launch_raycast into scratch maps).  RGBA, alpha 0.
+hipError_t launch_render_depth(uchar4 *out, const float *depth, int npix, float near_plane, float far_plane,
+                               hipStream_t s);
+// exactly one of data (row stride `stride` elements) and codes (row stride `stride` bytes) is non-null
+hipError_t launch_render_track(uchar4 *out, const kfh_track_data *data, const signed char *codes, int stride, int w,
+                               int h, hipStream_t s);
+hipError_t launch_render_shade(uchar4 *out, const float4 *vertex, const float4 *normal, int npix,
+                               const float light[3], const float ambient[3], hipStream_t s);
+// view = pose * inverse camera matrix, written to device memory for launch_raycast
+hipError_t launch_view_from_pose(Mat4 *d_view, const Mat4 &pose, const float k[4], hipStream_t s);
 
 }  // namespace kfh
 #endif

@@ -1076,6 +1076,7 @@ __global__ __launch_bounds__(64 * (1 + PW)) void k_icp_iteration(const float *__
         float acc[32];
 #pragma unroll
         for (int i = 0; i < 32; ++i) acc[i] = 0.0f;
+        int code[PPT];
 #pragma unroll
         for (int k = 0; k < PPT; ++k) {
             f3 referenceNormal, refVertex;
@@ -1102,6 +1103,7 @@ __global__ __launch_bounds__(64 * (1 + PW)) void k_icp_iteration(const float *__
                                : dist_bad              ? -4
                                : normal_bad            ? -5
                                                        : 1;
+            code[k] = result;
             const bool valid = result == 1;
             const f3 c = cross3(projectedVertex[k], referenceNormal);
             const float error = valid ? dot3(referenceNormal, diff) : 0.f;
@@ -1136,6 +1138,11 @@ __global__ __launch_bounds__(64 * (1 + PW)) void k_icp_iteration(const float *__
         }
         KFH_STAMP(5, 1);
         KFH_STAMP(9, 4);
+        if (a.result_out != nullptr) {               // only when the tracking render was asked for
+#pragma unroll
+            for (int k = 0; k < PPT; ++k)
+                if (live[k]) a.result_out[x + yy[k] * a.result_stride] = (signed char)code[k];
+        }
         const float total = wave_reduce32(acc);
         if ((lane & 1) == 0) sh.part[pw][lane >> 1] = total;
         KFH_STAMP(10, 4);
@@ -1284,6 +1291,7 @@ hipError_t launch_track_reduce(Ctrl *scratch_ctrl, float *partials, float *sums,
     a.dist_threshold = dist_threshold; a.normal_threshold = normal_threshold;
     a.icp_threshold = 0.f;
     a.track_out = track_out; a.track_stride = track_stride;
+    a.result_out = nullptr; a.result_stride = 0;
     a.stamps = nullptr;
     hipError_t e = launch_icp_iteration(a, s);
     if (e != hipSuccess) return e;
@@ -2230,6 +2238,110 @@ hipError_t launch_composite(float4 *vertex, float4 *normal, float *ray_t, float4
                             const float4 *v_parts, const float4 *n_parts, int n, int npix, hipStream_t s) {
     hipLaunchKernelGGL(k_composite, dim3((npix + 255) / 256), dim3(256), 0, s, vertex, normal, ray_t, ref_tn, t_parts,
                        v_parts, n_parts, n, npix);
+    return hipGetLastError();
+}
+
+// ---- GUI images -------------------------------------------------------------------------------------
+// gs2rgb of the reference renderer: hue ramp with value 0.75 and saturation 0.6667, evaluated in double
+__device__ inline uchar4 hue_ramp(double h) {
+    const double v = 0.75, m = 0.25, sv = 0.6667;
+    h *= 6.0;
+    const int sextant = (int)h;
+    const double fract = h - sextant;
+    const double vsf = v * sv * fract;
+    const double mid1 = m + vsf, mid2 = v - vsf;
+    double r = 0, g = 0, b = 0;
+    switch (sextant) {
+        case 0: r = v; g = mid1; b = m; break;
+        case 1: r = mid2; g = v; b = m; break;
+        case 2: r = m; g = v; b = mid1; break;
+        case 3: r = m; g = mid2; b = v; break;
+        case 4: r = mid1; g = m; b = v; break;
+        case 5: r = v; g = m; b = mid2; break;
+        default: break;                               // h == 1 exactly: black, as in the reference
+    }
+    return make_uchar4((unsigned char)(r * 255), (unsigned char)(g * 255), (unsigned char)(b * 255), 0);
+}
+
+// renderDepthKernel
+__global__ __launch_bounds__(256) void k_render_depth(uchar4 *__restrict__ out, const float *__restrict__ depth,
+                                                      int npix, float near_plane, float far_plane) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= npix) return;
+    const float range_scale = 1 / (far_plane - near_plane);
+    const float d = depth[p];
+    uchar4 c;
+    if (d < near_plane) c = make_uchar4(255, 255, 255, 0);
+    else if (d > far_plane) c = make_uchar4(0, 0, 0, 0);
+    else c = hue_ramp((d - near_plane) * range_scale);
+    out[p] = c;
+}
+
+// renderTrackKernel
+__global__ __launch_bounds__(256) void k_render_track(uchar4 *__restrict__ out, const kfh_track_data *__restrict__ data,
+                                                      const signed char *__restrict__ codes, int stride, int w, int h) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= w || y >= h) return;
+    const int result = data ? data[x + (size_t)y * stride].result : (int)codes[x + (size_t)y * stride];
+    uchar4 c;
+    switch (result) {
+        case 1: c = make_uchar4(128, 128, 128, 0); break;    // ok
+        case -1: c = make_uchar4(0, 0, 0, 0); break;         // no input
+        case -2: c = make_uchar4(255, 0, 0, 0); break;       // not in image
+        case -3: c = make_uchar4(0, 255, 0, 0); break;       // no correspondence
+        case -4: c = make_uchar4(0, 0, 255, 0); break;       // too far away
+        case -5: c = make_uchar4(255, 255, 0, 0); break;     // wrong normal
+        default: c = make_uchar4(255, 128, 128, 0); break;
+    }
+    out[x + (size_t)y * w] = c;
+}
+
+// Shading half of renderVolumeKernel.  The raycast launch before it stored the hit point and the normalised
+// TSDF gradient, and an invalid normal wherever the ray missed or the gradient vanished.
+__global__ __launch_bounds__(256) void k_render_shade(uchar4 *__restrict__ out, const float4 *__restrict__ vertex,
+                                                      const float4 *__restrict__ normal, int npix, f3 light,
+                                                      f3 ambient) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= npix) return;
+    const float4 n4 = normal[p], v4 = vertex[p];
+    uchar4 c = make_uchar4(0, 0, 0, 0);
+    if (n4.x != KFH_INVALID) {
+        const f3 diff = normalize3(light - mk3(v4.x, v4.y, v4.z));
+        const float dir = fmaxf(dot3(mk3(n4.x, n4.y, n4.z), diff), 0.f);
+        const float r = fminf(fmaxf(dir + ambient.x, 0.f), 1.f) * 255;
+        const float g = fminf(fmaxf(dir + ambient.y, 0.f), 1.f) * 255;
+        const float b = fminf(fmaxf(dir + ambient.z, 0.f), 1.f) * 255;
+        c = make_uchar4((unsigned char)r, (unsigned char)g, (unsigned char)b, 0);
+    }
+    out[p] = c;
+}
+
+__global__ void k_view_from_pose(Mat4 *out, Mat4 pose, float fx, float fy, float cx, float cy) {
+    if (threadIdx.x == 0) *out = mat_mul(pose, inverse_camera_matrix(fx, fy, cx, cy));
+}
+
+hipError_t launch_render_depth(uchar4 *out, const float *depth, int npix, float near_plane, float far_plane,
+                               hipStream_t s) {
+    hipLaunchKernelGGL(k_render_depth, dim3((npix + 255) / 256), dim3(256), 0, s, out, depth, npix, near_plane, far_plane);
+    return hipGetLastError();
+}
+
+hipError_t launch_render_track(uchar4 *out, const kfh_track_data *data, const signed char *codes, int stride, int w,
+                               int h, hipStream_t s) {
+    if ((data == nullptr) == (codes == nullptr) || stride < w) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_render_track, dim3((w + 63) / 64, (h + 3) / 4), dim3(256), 0, s, out, data, codes, stride, w, h);
+    return hipGetLastError();
+}
+
+hipError_t launch_render_shade(uchar4 *out, const float4 *vertex, const float4 *normal, int npix,
+                               const float light[3], const float ambient[3], hipStream_t s) {
+    hipLaunchKernelGGL(k_render_shade, dim3((npix + 255) / 256), dim3(256), 0, s, out, vertex, normal, npix,
+                       mk3(light[0], light[1], light[2]), mk3(ambient[0], ambient[1], ambient[2]));
+    return hipGetLastError();
+}
+
+hipError_t launch_view_from_pose(Mat4 *d_view, const Mat4 &pose, const float k[4], hipStream_t s) {
+    hipLaunchKernelGGL(k_view_from_pose, dim3(1), dim3(64), 0, s, d_view, pose, k[0], k[1], k[2], k[3]);
     return hipGetLastError();
 }
 

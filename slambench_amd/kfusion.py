@@ -156,6 +156,21 @@ class KFusion:
                                           C.c_size_t(nbytes)))
         return out
 
+    def enable_track_render(self, enabled=True):
+        """Tracking stores its per-pixel result codes from now on (needed by render(RENDER_TRACK))."""
+        native.check(self._L.kfh_enable_track_render(self._ctx, int(bool(enabled))))
+
+    def render(self, image, view_pose=None):
+        """One of the plugin's GUI images as uint8 [h, w, 4] (RGBA, alpha 0); synchronises.
+        view_pose (4x4 camera-to-world, RENDER_VOLUME only): None renders from the current pose."""
+        out = np.empty((self.height, self.width, 4), np.uint8)
+        vp = None
+        if view_pose is not None:
+            vp = np.ascontiguousarray(view_pose, dtype=np.float32).reshape(16)
+        native.check(self._L.kfh_render(self._ctx, int(image), None if vp is None else vp.ctypes.data_as(C.c_void_p),
+                                        out.ctypes.data_as(C.c_void_p), C.c_size_t(out.nbytes)))
+        return out
+
     def set_timing(self, mode):
         """0 off, 1 (or True) all four phases, 2 integration only."""
         native.check(self._L.kfh_set_timing(self._ctx, int(mode)))

@@ -14,6 +14,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libkfusion_hip_core.so")
 KFH_OK = 0
 BUF_FLOAT_DEPTH, BUF_SCALED_DEPTH, BUF_INPUT_VERTEX, BUF_INPUT_NORMAL = 0, 1, 2, 3
 BUF_MODEL_VERTEX, BUF_MODEL_NORMAL, BUF_VOLUME, BUF_RAY_T, BUF_BRICK_MARKS = 4, 5, 6, 7, 8
+RENDER_DEPTH, RENDER_TRACK, RENDER_VOLUME = 0, 1, 2
 
 # every symbol include/kfusion_hip.h declares
 EXPORTED_SYMBOLS = (
@@ -25,6 +26,8 @@ EXPORTED_SYMBOLS = (
     "kfh_get_pose", "kfh_set_pose", "kfh_get_status", "kfh_frame_index", "kfh_compute_size",
     "kfh_download", "kfh_device_ptr", "kfh_stream", "kfh_set_timing", "kfh_phase_ms", "kfh_phase_ms_frame",
     "kfh_raycast_slab", "kfh_composite_slabs",
+    "kfh_render", "kfh_render_device", "kfh_enable_track_render",
+    "kfh_k_render_depth", "kfh_k_render_track", "kfh_k_render_volume",
     "kfh_k_preprocess", "kfh_k_bilateral", "kfh_k_half_sample", "kfh_k_vertex_normal",
     "kfh_k_track_reduce", "kfh_k_update_pose", "kfh_k_integrate", "kfh_k_raycast",
 )
@@ -82,6 +85,11 @@ def lib():
         "kfh_k_update_pose": [vp, vp, vp, vp, f32, vp],
         "kfh_k_integrate": [vp, vp, vp, i32, i32, vp, i32, i32, vp, vp, f32, f32, vp],
         "kfh_k_raycast": [vp, vp, i32, i32, vp, vp, vp, vp, f32, f32, f32, f32, vp],
+        "kfh_render": [vp, i32, vp, vp, C.c_size_t], "kfh_render_device": [vp, i32, vp, vp],
+        "kfh_enable_track_render": [vp, i32],
+        "kfh_k_render_depth": [vp, vp, i32, i32, f32, f32, vp],
+        "kfh_k_render_track": [vp, vp, i32, i32, i32, vp],
+        "kfh_k_render_volume": [vp, i32, i32, vp, vp, vp, vp, f32, f32, f32, f32, vp, vp, vp],
     }
     for name, argtypes in sig.items():
         fn = getattr(L, name)
