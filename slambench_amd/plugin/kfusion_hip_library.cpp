@@ -22,6 +22,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <vector>
@@ -50,6 +51,13 @@ kfh_context *ctx = nullptr;
 slambench::io::DepthSensor *depth_sensor = nullptr;
 slambench::outputs::Output *pose_output = nullptr;
 slambench::outputs::Output *pointcloud_output = nullptr;
+// the three pictures of the kfusion GUI (renderDepthKernel, renderTrackKernel, renderVolumeKernel)
+slambench::outputs::Output *depth_frame_output = nullptr, *track_frame_output = nullptr, *render_frame_output = nullptr;
+std::vector<uint8_t> depth_image, track_image, volume_image;   // RGBA of the compute size, filled in the Render phase
+bool depth_image_fresh = false, track_image_fresh = false, volume_image_fresh = false;
+bool track_codes_on = false;
+bool render_always = false;    // KFH_RENDER_ALWAYS: render like the reference, whether or not anybody looks
+int image_w = 0, image_h = 0;
 std::vector<uint16_t> depth_frame;
 bool depth_ready = false;
 int frame_counter = 0;
@@ -133,6 +141,22 @@ bool sb_init_slam_system(SLAMBenchLibraryHelper *slam_settings) {
     pointcloud_output = new slambench::outputs::Output("PointCloud", slambench::values::VT_POINTCLOUD, true);
     pointcloud_output->SetKeepOnlyMostRecent(true);
     slam_settings->GetOutputManager().RegisterOutput(pointcloud_output);
+
+    if (!report("kfh_compute_size", kfh_compute_size(ctx, &image_w, &image_h))) return false;
+    const size_t image_bytes = (size_t)image_w * image_h * 4;
+    depth_image.assign(image_bytes, 0);
+    track_image.assign(image_bytes, 0);
+    volume_image.assign(image_bytes, 0);
+    depth_image_fresh = track_image_fresh = volume_image_fresh = false;
+    track_codes_on = false;
+    render_always = std::getenv("KFH_RENDER_ALWAYS") != nullptr;
+    slambench::outputs::Output **frame_outputs[3] = {&depth_frame_output, &track_frame_output, &render_frame_output};
+    const char *const frame_names[3] = {"Depth Frame", "Tracking Frame", "Rendered frame"};
+    for (int i = 0; i < 3; ++i) {
+        *frame_outputs[i] = new slambench::outputs::Output(frame_names[i], slambench::values::VT_FRAME);
+        (*frame_outputs[i])->SetKeepOnlyMostRecent(true);
+        slam_settings->GetOutputManager().RegisterOutput(*frame_outputs[i]);
+    }
     return true;
 }
 
@@ -169,7 +193,32 @@ bool sb_process_once(SLAMBenchLibraryHelper *slam_settings) {
     // host timers without a device synchronisation, framework/shared/src/metrics/DurationMetric.cpp:65-71).
     ok = ok && report("kfh_sync", kfh_sync(ctx));
     phase[3]->End();
-    phase[4]->Begin();                                // no debug rendering in this plugin
+    // Render: the depth and tracking pictures every frame, the volume picture every rendering-rate frames, as
+    // the Duration_Render column of the reference's logs shows (two levels, the high one on rows 1, 5, 9, ...).
+    // Unlike the reference, a picture nobody has activated is not drawn (KFH_RENDER_ALWAYS=1 draws all three).
+    phase[4]->Begin();
+    {
+        const bool want_depth = render_always || depth_frame_output->IsActive();
+        const bool want_track = render_always || track_frame_output->IsActive();
+        const bool want_volume = (render_always || render_frame_output->IsActive()) && rendering_rate > 0 &&
+                                 (frame_counter % rendering_rate) == 0;
+        if (want_depth) {
+            ok = ok && report("kfh_render(depth)", kfh_render(ctx, KFH_RENDER_DEPTH, nullptr, depth_image.data(), depth_image.size()));
+            depth_image_fresh = ok;
+        }
+        if (want_track && track_codes_on) {
+            ok = ok && report("kfh_render(track)", kfh_render(ctx, KFH_RENDER_TRACK, nullptr, track_image.data(), track_image.size()));
+            track_image_fresh = ok;
+        }
+        if (want_track != track_codes_on) {          // tracking stores its result codes from the next frame on
+            ok = ok && report("kfh_enable_track_render", kfh_enable_track_render(ctx, want_track ? 1 : 0));
+            track_codes_on = want_track;
+        }
+        if (want_volume) {
+            ok = ok && report("kfh_render(volume)", kfh_render(ctx, KFH_RENDER_VOLUME, nullptr, volume_image.data(), volume_image.size()));
+            volume_image_fresh = ok;
+        }
+    }
     phase[4]->End();
     ok = ok && report("kfh_end_frame", kfh_end_frame(ctx));
     depth_ready = false;
@@ -201,6 +250,16 @@ bool sb_update_outputs(SLAMBenchLibraryHelper *lib, const slambench::TimeStamp *
             if (v[0] != 0.f || v[1] != 0.f || v[2] != 0.f) cloud->AddPoint({v[0], v[1], v[2]});
         }
         pointcloud_output->AddPoint(ts, cloud);
+    }
+    struct { slambench::outputs::Output *out; std::vector<uint8_t> *image; bool *fresh; } pictures[3] = {
+        {depth_frame_output, &depth_image, &depth_image_fresh},
+        {track_frame_output, &track_image, &track_image_fresh},
+        {render_frame_output, &volume_image, &volume_image_fresh}};
+    for (auto &p : pictures) {
+        if (!p.out->IsActive() || !*p.fresh) continue;
+        p.out->AddPoint(ts, new slambench::values::FrameValue((uint32_t)image_w, (uint32_t)image_h,
+                                                                slambench::io::pixelformat::RGBA_IIII_8888, p.image->data()));
+        *p.fresh = false;
     }
     return true;
 }

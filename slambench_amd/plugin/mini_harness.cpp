@@ -63,7 +63,7 @@ static bool parse_plugin_options(SLAMBenchLibraryHelper *lib, const std::vector<
 }
 
 int main(int argc, char **argv) {
-    std::string input, library, log_file;
+    std::string input, library, log_file, dump_frames;
     int frame_limit = 0;
     std::vector<std::string> plugin_args;
     for (int i = 1; i < argc; ++i) {
@@ -73,10 +73,11 @@ int main(int argc, char **argv) {
         else if (a == "-load" || a == "--load-library") library = need("-load");
         else if (a == "-o" || a == "--log-file") log_file = need("-o");
         else if (a == "-fl" || a == "--frame-limit") frame_limit = std::atoi(need("-fl").c_str());
+        else if (a == "--dump-frames") dump_frames = need("--dump-frames");
         else plugin_args.push_back(a);
     }
     if (input.empty() || library.empty()) {
-        std::fprintf(stderr, "usage: %s -i stream.{slam,kfd} -load libkfusion-hip-library.so [-fl N] [-o log] [plugin options]\n", argv[0]);
+        std::fprintf(stderr, "usage: %s -i stream.{slam,kfd} -load libkfusion-hip-library.so [-fl N] [-o log] [--dump-frames DIR] [plugin options]\n", argv[0]);
         return 1;
     }
 
@@ -220,6 +221,10 @@ int main(int argc, char **argv) {
     auto *trajectory = lib->GetOutputManager().GetMainOutput(slambench::values::VT_POSE);
     if (!trajectory) { std::fprintf(stderr, "Algo does not provide a main pose output\n"); return 1; }
     trajectory->SetActive(true);
+    // what the GUI does when a picture is ticked: activate the frame outputs; their last values are written at the end
+    if (!dump_frames.empty())
+        for (auto &kv : lib->GetOutputManager())
+            if (kv.second->GetType() == slambench::values::VT_FRAME) kv.second->SetActive(true);
 
     *log << "\nStatistics:\n=================\n\nFrame Number\tTimestamp\tDuration_Frame";
     for (auto *p : lib->GetMetricManager().GetPhases()) *log << "\tDuration_" << p->GetName();
@@ -284,6 +289,20 @@ int main(int argc, char **argv) {
             fr.Timestamp = ts;
             if (feed(&fr, ts) < 0) return 1;
             if (frame_limit > 0 && processed >= (unsigned)frame_limit) break;
+        }
+    }
+    if (!dump_frames.empty()) {
+        for (auto &kv : lib->GetOutputManager()) {
+            if (kv.second->GetType() != slambench::values::VT_FRAME) continue;
+            auto *out = static_cast<slambench::outputs::Output *>(kv.second);
+            if (out->Empty()) continue;
+            const auto *fv = static_cast<const slambench::values::FrameValue *>(out->GetMostRecentValue().second);
+            std::string name = kv.first;
+            for (char &ch : name) if (ch == ' ') ch = '_';
+            // raw RGBA rows, preceded by "width height\n"
+            std::ofstream f(dump_frames + "/" + name + ".rgba", std::ios::binary);
+            f << fv->GetWidth() << " " << fv->GetHeight() << "\n";
+            f.write((const char *)fv->GetData(), (std::streamsize)fv->GetWidth() * fv->GetHeight() * 4);
         }
     }
     if (!lib->c_sb_clean_slam_system()) { std::fprintf(stderr, "Algorithm cleaning failed.\n"); return 1; }

@@ -84,3 +84,38 @@ def test_slam_file_input_matches_kfd_input(torch_cuda, tmp_path):
     cols = harness.parse_log(text)[1]
     assert cols[2:7] == list(harness.ACCURACY_COLUMNS)
     assert acc[-1]["ATE_RMSE"] < 0.05
+
+
+def test_plugin_frame_outputs(torch_cuda, tmp_path):
+    """With the three picture outputs active (what ticking them in the reference GUI does) the plugin publishes
+    RGBA FrameValues of the compute size; they must equal the images the core renders for the same stream."""
+    from slambench_amd import native
+    n = 9                                                   # the volume picture is drawn on frames 0, 4 and 8
+    intr = (481.2, 480.0, 319.5, 239.5)
+    depth, gt, ts = synth.make_sequence(n, seed=1, intrinsics=intr)
+    path = str(tmp_path / "stream.kfd")
+    harness.write_kfd(path, depth, ts, intr, 0.001)
+    out_dir = tmp_path / "frames"
+    out_dir.mkdir()
+    r = harness.run_mini_harness(path, ["-c", "4", "-v", "128,128,128", "--dump-frames", str(out_dir)])
+    assert r.returncode == 0, r.stderr
+    _, cols, rows = harness.parse_log(r.stdout)
+    render = rows[:, cols.index("Duration_Render")]
+    assert (render > 0).all()
+
+    def load(name):
+        with open(out_dir / name, "rb") as f:
+            w, h = (int(v) for v in f.readline().split())
+            return np.frombuffer(f.read(), np.uint8).reshape(h, w, 4)
+
+    w, h = 640, 480
+    intr_rt = tuple(float(np.float32(v / s) * np.float32(s)) for v, s in zip(intr, (w, h, w, h)))
+    kf = KFusion(KFusionConfig(intrinsics=intr_rt, compute_size_ratio=4, volume_resolution=(128, 128, 128)))
+    kf.enable_track_render(True)
+    for i in range(n):
+        kf.process_frame(depth[i])
+    assert np.array_equal(load("Depth_Frame.rgba"), kf.render(native.RENDER_DEPTH))
+    assert np.array_equal(load("Rendered_frame.rgba"), kf.render(native.RENDER_VOLUME))
+    # the plugin starts storing result codes one frame after the output was activated; by frame 8 both agree
+    assert np.array_equal(load("Tracking_Frame.rgba"), kf.render(native.RENDER_TRACK))
+    kf.close()
