@@ -36,6 +36,11 @@ def parse_args():
                     help="rendered frames; the stream plays them forwards then backwards")
     ap.add_argument("--cpu-frames", type=int, default=12, help="frames of the CPU baseline sample (0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=16)
+    ap.add_argument("--cpu-frames-1t", type=int, default=5,
+                    help="frames of the additional single-threaded CPU sample (0 = skip)")
+    ap.add_argument("--host-frames", action="store_true",
+                    help="also time the stream with frames handed over in host memory (one H2D copy per frame); "
+                         "reported as pcie_inclusive_frames_per_s, never as value")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--mode", choices=["replicas", "zslab"], default="replicas",
                     help="N>1: one independent sequence per GPU (default), or ONE sequence whose volume is "
@@ -54,8 +59,8 @@ def ping_pong(n_unique, count):
 
 def cpu_baseline(cfg, depth, frames, threads):
     """The oracle (a port of the kfusion C++ path) timed on this box's host cores on the first frames."""
-    os.environ["OMP_NUM_THREADS"] = str(threads)
     from oracle import kf_ref
+    threads = kf_ref.set_threads(threads)
     ref = kf_ref.KFusionRef(cfg.to_c(kf_ref.Config))
     poses = []
     t0 = time.perf_counter()
@@ -66,7 +71,7 @@ def cpu_baseline(cfg, depth, frames, threads):
         poses.append(ref.pose.copy())
     dt = time.perf_counter() - t0
     ref.close()
-    return frames / dt, np.stack(poses), phases / frames
+    return frames / dt, np.stack(poses), phases / frames, threads
 
 
 def main():
@@ -101,7 +106,7 @@ def main():
     n_unique = max(8, min(a.unique_frames, total))
     seed = 1 if zslab else 1 + rank          # sharded: every rank sees the same frames (broadcast input)
     depth, gt, ts = synth.make_sequence(n_unique, seed=seed, intrinsics=TUM_FR1_DEPTH_INTRINSICS, noise=True)
-    order = ping_pong(n_unique, total)
+    order = ping_pong(n_unique, total + 300)
     d_depth = torch.from_numpy(depth.view(np.int16)).cuda()      # every frame resident in HBM
     frame_ptrs = [int(d_depth[i].data_ptr()) for i in range(n_unique)]
 
@@ -157,6 +162,18 @@ def main():
     est = np.stack([kf.status(f)["pose"] for f in range(n_fwd)]) if total <= 4096 else None
     ate_hip = ate(est, gt[:n_fwd], ts[:n_fwd], ts[:n_fwd])["rmse"] if est is not None else None
 
+    # frames handed over in host memory (after the records of the timed region have been read: it moves the
+    # context's frame counter on)
+    pcie_fps = None
+    if a.host_frames and not zslab:
+        n_host = min(a.steps, 300)
+        kf.sync()
+        th = time.perf_counter()
+        for i in range(n_host):
+            kf.process_frame(depth[order[total + i]])     # numpy frame: kfh_upload_depth per frame
+        kf.sync()
+        pcie_fps = n_host / (time.perf_counter() - th)
+
     result = None
     if rank == 0:
         traffic = None
@@ -193,6 +210,7 @@ def main():
             "integrate_ms": t_int * 1e3 if integ_ms.size else None,
             "tracked_fraction": tracked / max(1, total - first),
             "ate_rmse_m": ate_hip,
+            "pcie_inclusive_frames_per_s": pcie_fps,
             "roofline": {
                 "kernel": "k_integrate",
                 "bound": "hbm",
@@ -211,7 +229,7 @@ def main():
         if not a.no_cpu_baseline and a.cpu_frames > 0 and world == 1:
             threads = max(1, min(a.cpu_threads, os.cpu_count() or 1))
             n_cpu = min(a.cpu_frames, n_unique)
-            fps_cpu, poses_cpu, phases = cpu_baseline(cfg, depth, n_cpu, threads)
+            fps_cpu, poses_cpu, phases, threads = cpu_baseline(cfg, depth, n_cpu, threads)
             d = np.linalg.norm(est[:n_cpu, :3, 3] - poses_cpu[:, :3, 3], axis=1) if est is not None else None
             a_cpu = ate(poses_cpu, gt[:n_cpu], ts[:n_cpu], ts[:n_cpu])["rmse"]
             a_hip = ate(est[:n_cpu], gt[:n_cpu], ts[:n_cpu], ts[:n_cpu])["rmse"] if est is not None else None
@@ -221,6 +239,16 @@ def main():
                 "phase_seconds": {"preprocessing": phases[0], "tracking": phases[1], "integration": phases[2],
                                   "raycasting": phases[3]},
             }
+            if a.cpu_frames_1t > 0:
+                # the single-threaded figure (what the reference calls kfusion-cpp next to kfusion-openmp)
+                n1 = min(a.cpu_frames_1t, n_unique)
+                fps_1t, _, phases_1t, _ = cpu_baseline(cfg, depth, n1, 1)
+                result["cpu_baseline_single_thread"] = {
+                    "value": fps_1t, "unit": "frames/s", "cores": 1, "kind": "port",
+                    "sample": "first %d frames of the same stream through the CPU oracle, one thread" % n1,
+                    "phase_seconds": {"preprocessing": phases_1t[0], "tracking": phases_1t[1],
+                                      "integration": phases_1t[2], "raycasting": phases_1t[3]},
+                }
             result["ate_delta_vs_cpu_m"] = abs(a_hip - a_cpu) if a_hip is not None else None
             result["max_position_delta_vs_cpu_m"] = float(d.max()) if d is not None else None
     kf.close()

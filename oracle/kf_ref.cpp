@@ -20,6 +20,10 @@
 #include <cstring>
 #include <vector>
 
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
 namespace {
 
 constexpr float KF_INVALID = -2.0f;
@@ -832,6 +836,17 @@ int kfr_process_frame(kfr_context *c, const uint16_t *depth, double *phase_secon
 void kfr_get_pose(const kfr_context *c, float pose[16]) { store_m4(pose, c->pose); }
 void kfr_set_pose(kfr_context *c, const float pose[16]) { c->pose = load_m4(pose); }
 int kfr_frame_index(const kfr_context *c) { return c->frame; }
+
+/* Worker threads of the parallel loops (n <= 0: leave as is); returns the count in force. */
+int kfr_set_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+    return omp_get_max_threads();
+#else
+    (void)n;
+    return 1;
+#endif
+}
 const float *kfr_float_depth(const kfr_context *c) { return c->float_depth.data(); }
 const float *kfr_scaled_depth(const kfr_context *c, int l) { return c->scaled_depth[l].data(); }
 const float *kfr_input_vertex(const kfr_context *c, int l) { return c->in_vertex[l].data(); }

@@ -94,6 +94,7 @@ int  kfr_process_frame(kfr_context *c, const uint16_t *depth, double *phase_seco
 void kfr_get_pose(const kfr_context *c, float pose[16]);
 void kfr_set_pose(kfr_context *c, const float pose[16]);
 int  kfr_frame_index(const kfr_context *c);
+int  kfr_set_threads(int n);   /* OpenMP worker threads (n <= 0: query only); returns the count in force */
 /* buffer accessors (pointers stay owned by the context) */
 const float   *kfr_float_depth(const kfr_context *c);
 const float   *kfr_scaled_depth(const kfr_context *c, int level);

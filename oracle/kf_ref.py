@@ -71,10 +71,17 @@ def lib():
         for name in ("kfr_scaled_depth", "kfr_input_vertex", "kfr_input_normal"):
             getattr(L, name).restype = C.c_void_p
             getattr(L, name).argtypes = [C.c_void_p, C.c_int]
+        L.kfr_set_threads.restype = C.c_int
+        L.kfr_set_threads.argtypes = [C.c_int]
         L.kfr_update_pose.restype = C.c_int
         L.kfr_check_pose.restype = C.c_int
         _lib = L
     return _lib
+
+
+def set_threads(n=0):
+    """OpenMP worker threads of the oracle (0: query only); returns the count in force."""
+    return int(lib().kfr_set_threads(int(n)))
 
 
 def _p(a):

@@ -61,8 +61,12 @@ struct kfh_context {
     int compute_units = 256;
     hipStream_t stream = nullptr;
 
-    uint16_t *h_depth_pinned = nullptr;
-    uint16_t *d_depth_in = nullptr;        // staging owned by the context
+    // Two staging slots (pinned host + device) so that the host fills one while the device still reads the other
+    uint16_t *h_depth_pinned[2] = {nullptr, nullptr};
+    uint16_t *d_depth_in[2] = {nullptr, nullptr};
+    hipEvent_t ev_slot_free[2] = {nullptr, nullptr};   // recorded after the preprocessing launch that consumed the slot
+    bool slot_unread[2] = {false, false};  // uploaded, but no preprocessing launch has been queued on it yet
+    int upload_slot = 0;
     const uint16_t *d_depth_cur = nullptr; // frame to process (staging or caller-owned)
     // Depth images of the frame being processed: aliases of one of two buffer sets.  With `overlap` the
     // preprocessing of frame n + 1 runs on its own stream and writes the other set while frame n is still
@@ -138,8 +142,11 @@ hipError_t dev_alloc(T **p, size_t count) {
 }
 
 void free_all(kfh_context *c) {
-    if (c->h_depth_pinned) (void)hipHostFree(c->h_depth_pinned);
-    void *bufs[] = {c->d_depth_in, c->set_float_depth[0], c->set_float_depth[1], c->set_scaled[0][0],
+    for (int i = 0; i < 2; ++i) {
+        if (c->h_depth_pinned[i]) (void)hipHostFree(c->h_depth_pinned[i]);
+        if (c->ev_slot_free[i]) (void)hipEventDestroy(c->ev_slot_free[i]);
+    }
+    void *bufs[] = {c->d_depth_in[0], c->d_depth_in[1], c->set_float_depth[0], c->set_float_depth[1], c->set_scaled[0][0],
                     c->set_scaled[0][1], c->set_scaled[0][2], c->set_scaled[1][0], c->set_scaled[1][1],
                     c->set_scaled[1][2],
                     c->d_in_vertex[0], c->d_in_vertex[1], c->d_in_vertex[2], c->d_in_normal[0],
@@ -202,7 +209,9 @@ int init_state(kfh_context *c) {
     KFH_HIP(hipStreamSynchronize(c->stream));   // `init` lives on this stack frame
     KFH_HIP(launch_pose_derive(c->d_ctrl, c->k, 1, c->stream));
     c->frame = 0;
-    c->d_depth_cur = c->d_depth_in;
+    c->d_depth_cur = c->d_depth_in[0];
+    c->upload_slot = 0;
+    c->slot_unread[0] = c->slot_unread[1] = false;
     c->timed_first = -1;
     return KFH_OK;
 }
@@ -265,8 +274,11 @@ int kfh_create(const kfh_config *cfg, kfh_context **out) {
     const size_t nin = (size_t)cfg->input_width * cfg->input_height;
     hipError_t e = hipGetDevice(&c->device);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&c->h_depth_pinned), nin * sizeof(uint16_t), hipHostMallocDefault);
-    if (e == hipSuccess) e = dev_alloc(&c->d_depth_in, nin);
+    for (int i = 0; i < 2 && e == hipSuccess; ++i) {
+        e = hipHostMalloc(reinterpret_cast<void **>(&c->h_depth_pinned[i]), nin * sizeof(uint16_t), hipHostMallocDefault);
+        if (e == hipSuccess) e = dev_alloc(&c->d_depth_in[i], nin);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_slot_free[i], hipEventDisableTiming);
+    }
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->pre_stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_pre_done, hipEventDisableTiming);
     for (int i = 0; i < 2 && e == hipSuccess; ++i) {
@@ -346,13 +358,22 @@ int kfh_reset(kfh_context *c) {
 int kfh_upload_depth(kfh_context *c, const uint16_t *h_depth) {
     KFH_REQUIRE(c != nullptr && h_depth != nullptr, "NULL argument");
     const size_t bytes = (size_t)c->cfg.input_width * c->cfg.input_height * sizeof(uint16_t);
-    // The copy goes on the stream that preprocesses: the pinned buffer may still feed the previous frame's copy
-    // and the device staging buffer the previous frame's preprocessing launch.
+    // The copy goes on the stream that preprocesses.  The slot's pinned buffer fed the copy of the frame before
+    // the previous one and its device buffer that frame's preprocessing launch: wait for that launch only, so the
+    // host fills this slot while the device is still busy with the previous frame.
     hipStream_t ps = c->overlap ? c->pre_stream : c->stream;
-    KFH_HIP(hipStreamSynchronize(ps));
-    std::memcpy(c->h_depth_pinned, h_depth, bytes);
-    KFH_HIP(hipMemcpyAsync(c->d_depth_in, c->h_depth_pinned, bytes, hipMemcpyHostToDevice, ps));
-    c->d_depth_cur = c->d_depth_in;
+    const int slot = c->upload_slot;
+    c->upload_slot ^= 1;
+    if (c->slot_unread[slot]) KFH_HIP(hipStreamSynchronize(ps));   // two uploads ago nobody consumed this slot
+    else KFH_HIP(hipEventSynchronize(c->ev_slot_free[slot]));
+    c->slot_unread[slot] = true;
+    std::memcpy(c->h_depth_pinned[slot], h_depth, bytes);
+    static const bool use_copy_engine = std::getenv("KFH_UPLOAD_COPY_ENGINE") != nullptr;
+    if (use_copy_engine || bytes % 16 != 0)
+        KFH_HIP(hipMemcpyAsync(c->d_depth_in[slot], c->h_depth_pinned[slot], bytes, hipMemcpyHostToDevice, ps));
+    else
+        KFH_HIP(launch_stage_copy(c->d_depth_in[slot], c->h_depth_pinned[slot], bytes, ps));
+    c->d_depth_cur = c->d_depth_in[slot];
     return KFH_OK;
 }
 
@@ -379,6 +400,11 @@ int kfh_preprocess(kfh_context *c) {
                               c->cfg.input_width, c->cfg.compute_size_ratio, c->cfg.depth_divisor, c->d_scaled[1],
                               c->d_scaled[2], E_DELTA * 3, ps));
     c->depth_version++;
+    for (int i = 0; i < 2; ++i)      // a staging slot is free again once this launch has read it
+        if (c->d_depth_cur == c->d_depth_in[i]) {
+            KFH_HIP(hipEventRecord(c->ev_slot_free[i], ps));
+            c->slot_unread[i] = false;
+        }
     if (c->timing == 1) KFH_HIP(hipEventRecord(c->ev[c->frame % KFH_TIMING_RING][1], ps));
     if (side) {
         KFH_HIP(hipEventRecord(c->ev_pre_done, ps));

@@ -162,6 +162,8 @@ hipError_t launch_composite(float4 *vertex, float4 *normal, float *ray_t, float4
 void set_raycast_debug(unsigned long long *d_buffer);
 void set_integrate_debug(unsigned long long *d_buffer);
 hipError_t launch_fill_volume(short2 *vol, size_t nvox, hipStream_t s);
+// copy `bytes` (a multiple of 16) from pinned host memory to device memory with a kernel
+hipError_t launch_stage_copy(void *dst, const void *pinned_src, size_t bytes, hipStream_t s);
 // The three images of the reference GUI (renderDepthKernel, renderTrackKernel, the shading half of
 // renderVolumeKernel; its raycast half is launch_raycast into scratch maps).  RGBA, alpha 0.
 hipError_t launch_render_depth(uchar4 *out, const float *depth, int npix, float near_plane, float far_plane,

@@ -2241,6 +2241,24 @@ hipError_t launch_composite(float4 *vertex, float4 *normal, float *ray_t, float4
     return hipGetLastError();
 }
 
+// Host-to-device hand-over of a depth frame by the compute queue itself: the frame sits in pinned host memory,
+// every lane pulls 16 bytes over the bus.  A copy-engine transfer between two kernels of the same stream costs
+// two queue hand-overs, which is more than the transfer of a 0.6 MB frame takes.
+typedef unsigned int stage_u32x4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void k_stage_copy(stage_u32x4 *__restrict__ dst, const stage_u32x4 *__restrict__ src,
+                                                    size_t n16) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n16) dst[i] = __builtin_nontemporal_load(src + i);
+}
+
+hipError_t launch_stage_copy(void *dst, const void *pinned_src, size_t bytes, hipStream_t s) {
+    if (bytes % 16 != 0) return hipErrorInvalidValue;
+    const size_t n16 = bytes / 16;
+    hipLaunchKernelGGL(k_stage_copy, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, s, static_cast<stage_u32x4 *>(dst),
+                       static_cast<const stage_u32x4 *>(pinned_src), n16);
+    return hipGetLastError();
+}
+
 // ---- GUI images -------------------------------------------------------------------------------------
 // gs2rgb of the reference renderer: hue ramp with value 0.75 and saturation 0.6667, evaluated in double
 __device__ inline uchar4 hue_ramp(double h) {
