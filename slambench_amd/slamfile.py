@@ -97,8 +97,8 @@ def _write_sensor(f, s):
 
 
 def write_slam(path, sensors, frames):
-    """sensors: list of Sensor (index = position in the list); frames: iterable of (timestamp_s, sensor index,
-    bytes-like payload) in file order."""
+    """sensors: list of Sensor (index = position in the list); frames: iterable of (timestamp, sensor index,
+    bytes-like payload) in file order; a timestamp is seconds as a float or a (seconds, nanoseconds) tuple."""
     with open(path, "wb") as f:
         f.write(MAGIC)
         f.write(struct.pack("<II", VERSION, len(sensors)))
@@ -110,8 +110,12 @@ def write_slam(path, sensors, frames):
             if len(payload) != sensors[idx].frame_size:
                 raise ValueError("frame of sensor %d has %d bytes, expected %d" % (idx, len(payload),
                                                                                   sensors[idx].frame_size))
-            sec = int(ts)
-            f.write(struct.pack("<IIB", sec, int(round((ts - sec) * 1e9)), idx))
+            if isinstance(ts, tuple):                       # (seconds, nanoseconds), kept exactly
+                sec, nsec = ts
+            else:
+                sec = int(ts)
+                nsec = int(round((ts - sec) * 1e9))
+            f.write(struct.pack("<IIB", sec, nsec, idx))
             f.write(payload)
 
 
