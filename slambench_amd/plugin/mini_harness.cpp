@@ -65,6 +65,7 @@ static bool parse_plugin_options(SLAMBenchLibraryHelper *lib, const std::vector<
 int main(int argc, char **argv) {
     std::string input, library, log_file, dump_frames;
     int frame_limit = 0;
+    bool dse = false;
     std::vector<std::string> plugin_args;
     for (int i = 1; i < argc; ++i) {
         const std::string a = argv[i];
@@ -74,10 +75,11 @@ int main(int argc, char **argv) {
         else if (a == "-o" || a == "--log-file") log_file = need("-o");
         else if (a == "-fl" || a == "--frame-limit") frame_limit = std::atoi(need("-fl").c_str());
         else if (a == "--dump-frames") dump_frames = need("--dump-frames");
+        else if (a == "-dse" || a == "--dse") dse = true;
         else plugin_args.push_back(a);
     }
     if (input.empty() || library.empty()) {
-        std::fprintf(stderr, "usage: %s -i stream.{slam,kfd} -load libkfusion-hip-library.so [-fl N] [-o log] [--dump-frames DIR] [plugin options]\n", argv[0]);
+        std::fprintf(stderr, "usage: %s -i stream.{slam,kfd} -load libkfusion-hip-library.so [-fl N] [-o log] [--dump-frames DIR] [--dse] [plugin options]\n", argv[0]);
         return 1;
     }
 
@@ -201,6 +203,12 @@ int main(int argc, char **argv) {
     dlerror();
     if (!lib->c_sb_new_slam_configuration(lib)) { std::fprintf(stderr, "Configuration construction failed.\n"); return 1; }
     if (!parse_plugin_options(lib, plugin_args)) return 1;
+    if (dse) {                          // SLAMBenchConfiguration::PrintDse: the parameter space of the loaded library
+        std::cout << "libs:" << lib->GetIdentifier() << "\n";
+        for (Parameter *p : lib->getParameters())
+            std::cout << "argument:" << p->getLongOption() << "\n" << p->getStrDetails() << "\n";
+        return 0;
+    }
 
     std::ostream *log = &std::cout;
     std::ofstream log_stream;

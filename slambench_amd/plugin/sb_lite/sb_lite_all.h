@@ -22,6 +22,7 @@
 #include <sstream>
 #include <stdexcept>
 #include <string>
+#include <typeinfo>
 #include <utility>
 #include <vector>
 
@@ -78,6 +79,13 @@ struct Parameter {
     virtual void setValue(const char *) = 0;
     virtual void resetValue() = 0;
     virtual const std::string getStrValue() const = 0;
+    virtual const std::string getStrDefault() = 0;
+    // what `--dse` prints per parameter (Parameters.h:161-167)
+    virtual const std::string getStrDetails() {
+        std::ostringstream res;
+        res << "name:" << long_ << "\n" << "short-option:" << short_ << "\n" << "description:" << desc_ << "\n";
+        return res.str();
+    }
 private:
     std::string short_, long_, desc_;
 };
@@ -114,9 +122,48 @@ struct TypedParameter : Parameter {
     void setValue(const char *s) override { sb_lite_parse<T>(s, ptr_); }
     void resetValue() override { if (default_) *ptr_ = *default_; }
     const std::string getStrValue() const override { return sb_lite_to_string<T>(*ptr_); }
+    const std::string getStrDefault() override { return default_ ? sb_lite_to_string<T>(*default_) : "nullptr"; }
+    const std::string getStrDetails() override {          // Parameters.h:226-232
+        std::ostringstream res;
+        res << Parameter::getStrDetails() << "type:" << typeid(T).name() << "\n" << "default:" << getStrDefault() << "\n";
+        return res.str();
+    }
 private:
     const T *default_;
     T *ptr_;
+};
+
+// Parameters.h:392-410: a parameter with an explicit list of admissible values
+template <typename T>
+struct DiscretParameter : TypedParameter<T> {
+    DiscretParameter(std::vector<T> values, std::string short_option, std::string name, std::string description, T *ptr,
+                     const T *default_v)
+        : TypedParameter<T>(std::move(short_option), std::move(name), std::move(description), ptr, default_v),
+          values_(std::move(values)) {}
+    const std::string getStrDetails() override {
+        std::ostringstream res;
+        res << TypedParameter<T>::getStrDetails();
+        for (const T &v : values_) res << "values:" << sb_lite_to_string<T>(v) << "\n";
+        return res.str();
+    }
+private:
+    std::vector<T> values_;
+};
+
+// Parameters.h:413-429: a parameter with a range
+template <typename T>
+struct BoundedParameter : TypedParameter<T> {
+    BoundedParameter(T min, T max, std::string short_option, std::string name, std::string description, T *ptr,
+                     const T *default_v)
+        : TypedParameter<T>(std::move(short_option), std::move(name), std::move(description), ptr, default_v),
+          min_(min), max_(max) {}
+    const std::string getStrDetails() override {
+        std::ostringstream res;
+        res << TypedParameter<T>::getStrDetails() << "min:" << min_ << "\n" << "max:" << max_ << "\n";
+        return res.str();
+    }
+private:
+    T min_, max_;
 };
 
 // ParameterComponent.h:25-60

@@ -401,3 +401,42 @@ def test_icl_nuim_folder_import(tmp_path):
     assert np.allclose(flipped.gt_poses[0][:3, :3], np.diag([-1, -1, 1]), atol=1e-6)   # upside down, same z
     with pytest.raises(FileNotFoundError):
         datasets.load_icl_nuim(str(tmp_path))
+
+
+# ------------------------------------------------------------------------------------------ design-space sweeps
+def test_dse_dump_lists_the_plugin_parameters(tmp_path):
+    """`--dse` needs no GPU: the harness stops after the plugin has declared its parameters."""
+    from slambench_amd import dse, harness, synth
+    depth, gt, ts = synth.make_sequence(1, seed=1)
+    path = str(tmp_path / "s.kfd")
+    harness.write_kfd(path, depth, ts, (481.2, 480.0, 319.5, 239.5))
+    r = harness.run_mini_harness(path, ["--dse", "-c", "2"])
+    assert r.returncode == 0, r.stderr
+    assert r.stdout.startswith("libs:")
+    params = dse.parse_dse(r.stdout)
+    assert list(params)[:4] == ["compute-size-ratio", "integration-rate", "tracking-rate", "rendering-rate"]
+    assert params["compute-size-ratio"] == {"name": "compute-size-ratio", "short-option": "c",
+                                            "description": "Compute ratio", "type": "i", "default": "1"}
+    assert params["volume-resolution"]["default"] == "256,256,256"
+    assert params["mu"]["default"] == "0.1" and params["pyramid-level1"]["default"] == "10"
+
+
+def test_sweep_scheduler_keeps_one_process_per_gpu(tmp_path):
+    import sys, time
+    from slambench_amd import dse
+    points = dse.grid_points({"mu": ["0.05", "0.1", "0.2"], "volume-resolution": ["64", "128"]})
+    assert len(points) == 6 and points[0] == {"mu": "0.05", "volume-resolution": "64"} and points[1]["volume-resolution"] == "128"
+    marker = str(tmp_path)
+    code = ("import os,sys,time; g=os.environ['HIP_VISIBLE_DEVICES']; p=os.path.join(sys.argv[1], 'busy'+g); "
+            "assert not os.path.exists(p), 'two processes on one GPU'; open(p,'w').close(); time.sleep(0.2); "
+            "os.remove(p); print(g, sys.argv[2])")
+    t0 = time.time()
+    res = dse.run_sweep(points, lambda pt: [sys.executable, "-c", code, marker, pt["mu"] + "/" + pt["volume-resolution"]],
+                        gpus=[0, 1, 2], summarise_fn=lambda text: {"echo": text.split()[1]})
+    assert time.time() - t0 < 6 * 0.2 + 3                       # ran concurrently
+    assert all(r.returncode == 0 for r in res), [r.stderr for r in res]
+    assert [r.summary["echo"] for r in res] == [p["mu"] + "/" + p["volume-resolution"] for p in points]
+    assert {r.gpu for r in res} == {0, 1, 2}
+    assert all(r.stdout.split()[0] == str(r.gpu) for r in res)
+    bad = dse.run_sweep([{}], lambda pt: [sys.executable, "-c", "import sys; sys.exit(3)"], gpus=[0])
+    assert bad[0].returncode == 3 and bad[0].summary == {}

@@ -119,3 +119,21 @@ def test_plugin_frame_outputs(torch_cuda, tmp_path):
     # the plugin starts storing result codes one frame after the output was activated; by frame 8 both agree
     assert np.array_equal(load("Tracking_Frame.rgba"), kf.render(native.RENDER_TRACK))
     kf.close()
+
+
+def test_parameter_sweep_through_the_harness(torch_cuda, tmp_path):
+    """Two parameter points, one harness process each, on the one GPU of the box; ATE from the file's ground truth."""
+    from slambench_amd import dse, slamfile
+    n = 12
+    intr = (481.2, 480.0, 319.5, 239.5)
+    depth, gt, ts = synth.make_sequence(n, seed=1, intrinsics=intr)
+    slam = str(tmp_path / "s.slam")
+    slamfile.write_depth_sequence(slam, depth, ts, intr, gt_poses=gt, with_rgb_and_grey=False)
+    _, _, _, g, gts = slamfile.read_depth_sequence(slam)
+    points = dse.grid_points({"volume-resolution": ["64,64,64", "128,128,128"]})
+    res = dse.run_sweep(points, dse.mini_harness_cmd(slam, fixed_args=["-c", "4"]), gpus=[0],
+                        summarise_fn=lambda t: dse.summarise(t, g, gts))
+    assert [r.returncode for r in res] == [0, 0], [r.stderr for r in res]
+    assert all(r.summary["frames"] == n and r.summary["mean_frame_s"] > 0 for r in res)
+    assert res[1].summary["ate_rmse_m"] < 0.02                     # 128^3 tracks the synthetic room
+    assert res[0].summary["last_position"] != res[1].summary["last_position"]
