@@ -1210,19 +1210,101 @@ hipError_t launch_icp_iteration(const IcpIterArgs &a_in, hipStream_t s) {
     return hipGetLastError();
 }
 
-// Last launch of tracking: finalise the last iteration, then checkPoseKernel and the derived matrices.
-__global__ __launch_bounds__(KFH_SUM_THREADS) void k_icp_finish(FinishArgs a) {
+// End of tracking by one wavefront whose lanes all hold the same values: checkPoseKernel, the matrices derived
+// from the accepted pose, the control block, the first ICP record of the next frame and the status record.  The
+// new contents are assembled in LDS as dword images of the structures and copied out by all lanes (coalesced);
+// one lane storing some 270 dwords one after the other took several microseconds.
+constexpr int KFH_CTRL_HEAD_DWORDS = (int)(offsetof(Ctrl, icp) + sizeof(IcpState)) / 4;   // everything up to icp[0]
+constexpr int KFH_STATUS_DWORDS = (int)sizeof(kfh_frame_status) / 4;
+#define KFH_CTRL_DW(field) ((int)(offsetof(Ctrl, field) / 4))
+#define KFH_STATUS_DW(field) ((int)(offsetof(kfh_frame_status, field) / 4))
+
+__device__ inline void put_mat(unsigned *img, int at, const Mat4 &m) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) img[at + i] = __builtin_bit_cast(unsigned, m.m[i]);
+}
+
+__device__ inline void finish_tracking_wave(const FinishArgs &a, Mat4 pose, const Mat4 &old_pose, const float *sums_lds,
+                                            int iterations, int slow_solves, unsigned *ctrl_img, unsigned *status_img) {
+    const int lane = threadIdx.x & 63;
+    // checkPoseKernel
+    const float s0 = sums_lds[0], s28 = sums_lds[28];
+    const bool rejected = (sqrtf(s0 / s28) > 2e-2f) || (s28 / (float)(a.w * a.h) < a.track_threshold);
+    const int tracked = rejected ? 0 : 1;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) pose.m[i] = rejected ? old_pose.m[i] : pose.m[i];
+    const int integrated = ((tracked && (a.frame % a.integration_rate) == 0) || a.frame <= 3) ? 1 : 0;
+    const Mat4 inv = mat_inverse(pose);
+    const Mat4 view = mat_mul(pose, inverse_camera_matrix(a.k[0], a.k[1], a.k[2], a.k[3]));
+    const bool rc = a.will_raycast != 0;
+    if (lane == 0) {
+        put_mat(ctrl_img, KFH_CTRL_DW(pose), pose);
+        put_mat(ctrl_img, KFH_CTRL_DW(old_pose), pose);
+        put_mat(ctrl_img, KFH_CTRL_DW(inv_pose), inv);
+        put_mat(ctrl_img, KFH_CTRL_DW(view), view);
+        if (rc) {
+            // the model maps are re-rendered from this pose: K * inverse(raycast_pose) = K * inv
+            put_mat(ctrl_img, KFH_CTRL_DW(raycast_pose), pose);
+            put_mat(ctrl_img, KFH_CTRL_DW(raycast_view), view);
+            put_mat(ctrl_img, KFH_CTRL_DW(project_ref), mat_mul(camera_matrix(a.k[0], a.k[1], a.k[2], a.k[3]), inv));
+        }
+        ctrl_img[KFH_CTRL_DW(tracked)] = (unsigned)tracked;
+        ctrl_img[KFH_CTRL_DW(integrate_gate)] = (unsigned)integrated;
+        ctrl_img[KFH_CTRL_DW(frame)] = (unsigned)a.frame;
+        ctrl_img[KFH_CTRL_DW(ray_task_count)] = 0u;        // this frame's raycast appends its unfinished rays from here
+        ctrl_img[KFH_CTRL_DW(integrate_box_count)] = 0u;   // likewise the box list of this frame's integration
+        for (int i = 0; i < 3; ++i) ctrl_img[KFH_CTRL_DW(pad_) + i] = 0u;
+        // the record the next frame's first iteration starts from
+        const int st = KFH_CTRL_DW(icp);
+        put_mat(ctrl_img, st + (int)(offsetof(IcpState, pose) / 4), pose);
+        for (int i = (int)(offsetof(IcpState, pending_nblocks) / 4); i < (int)(sizeof(IcpState) / 4); ++i) ctrl_img[st + i] = 0u;
+        status_img[KFH_STATUS_DW(frame)] = (unsigned)a.frame;
+        status_img[KFH_STATUS_DW(tracked)] = (unsigned)tracked;
+        status_img[KFH_STATUS_DW(integrated)] = (unsigned)integrated;
+        status_img[KFH_STATUS_DW(raycasted)] = (unsigned)a.will_raycast;
+        put_mat(status_img, KFH_STATUS_DW(pose), pose);
+        status_img[KFH_STATUS_DW(icp_iterations)] = (unsigned)iterations;
+        status_img[KFH_STATUS_DW(slow_solves)] = (unsigned)slow_solves;
+    }
+    if (lane < 32) {
+        const unsigned v = __builtin_bit_cast(unsigned, sums_lds[lane]);
+        ctrl_img[KFH_CTRL_DW(sums) + lane] = v;
+        ctrl_img[KFH_CTRL_DW(icp) + (int)(offsetof(IcpState, sums) / 4) + lane] = v;
+        status_img[KFH_STATUS_DW(sums) + lane] = v;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    unsigned *c = reinterpret_cast<unsigned *>(a.ctrl);
+    for (int d = lane; d < KFH_CTRL_HEAD_DWORDS; d += 64) {
+        const bool raycast_field = (d >= KFH_CTRL_DW(raycast_pose) && d < KFH_CTRL_DW(inv_pose)) ||
+                                   (d >= KFH_CTRL_DW(raycast_view) && d < KFH_CTRL_DW(sums));
+        if (rc || !raycast_field) c[d] = ctrl_img[d];
+    }
+    if (a.status_ring) {
+        unsigned *st = reinterpret_cast<unsigned *>(a.status_ring + (a.frame % KFH_STATUS_RING));
+        for (int d = lane; d < KFH_STATUS_DWORDS; d += 64) st[d] = status_img[d];
+    }
+}
+
+// Last launch of tracking: finalise the last iteration, then checkPoseKernel and the derived matrices.  The
+// leading scalar parameters repeat fields of `a` so that they arrive preloaded in registers.
+__global__ __launch_bounds__(KFH_SUM_THREADS) void k_icp_finish(const float *__restrict__ pre_partials_in,
+                                                                Ctrl *__restrict__ pre_ctrl, int pre_pending_rows,
+                                                                int pre_seq, FinishArgs a) {
     __shared__ float slots[KFH_SUM_THREADS * 4];
     __shared__ float sums[32];
     __shared__ Mat4 pose;
     __shared__ int done_mask, iterations, slow_solves;
-    Ctrl *c = a.ctrl;
-    const IcpState *in = &c->icp[a.seq & 1];
+    __shared__ unsigned ctrl_img[KFH_CTRL_HEAD_DWORDS], status_img[KFH_STATUS_DWORDS];
+    Ctrl *c = pre_ctrl;
+    const IcpState *in = &c->icp[pre_seq & 1];
     PartialRows<KFH_SUM_THREADS> pr;
-    load_partial_rows<KFH_SUM_THREADS>(pr, a.partials_in, a.pending_rows);
+    load_partial_rows<KFH_SUM_THREADS>(pr, pre_partials_in, pre_pending_rows);
     const int pend = in->pending_nblocks;
     const Mat4 pose_in = in->pose;
-    if (pend > 0) stage_partial_rows<KFH_SUM_THREADS>(slots, pr, a.partials_in, pend);
+    const Mat4 old_pose = c->old_pose;
+    if (pend > 0) stage_partial_rows<KFH_SUM_THREADS>(slots, pr, pre_partials_in, pend);
     __syncthreads();
     if (threadIdx.x >= 64) return;
     icp_finalize_wave0<KFH_SUM_THREADS>(in, pose_in, pend, a.icp_threshold, slots, sums, &pose, &done_mask, &iterations,
@@ -1230,15 +1312,11 @@ __global__ __launch_bounds__(KFH_SUM_THREADS) void k_icp_finish(FinishArgs a) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    if (threadIdx.x == 0) {
-        c->pose = pose;
-        for (int i = 0; i < 32; ++i) c->sums[i] = sums[i];
-        finish_tracking(a, true, iterations, slow_solves);
-    }
+    finish_tracking_wave(a, pose, old_pose, sums, iterations, slow_solves, ctrl_img, status_img);
 }
 
 hipError_t launch_icp_finish(const FinishArgs &a, hipStream_t s) {
-    hipLaunchKernelGGL(k_icp_finish, dim3(1), dim3(KFH_SUM_THREADS), 0, s, a);
+    hipLaunchKernelGGL(k_icp_finish, dim3(1), dim3(KFH_SUM_THREADS), 0, s, a.partials_in, a.ctrl, a.pending_rows, a.seq, a);
     return hipGetLastError();
 }
 
