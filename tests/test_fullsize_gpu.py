@@ -1,0 +1,146 @@
+"""The benchmark configuration itself (640x480 depth, 512^3 TSDF over 8 m, ICP 10/5/4) on the GPU.
+
+Two kinds of checks: a direct comparison with the oracle on the first frames (the oracle needs a few tenths of
+a second per frame at this size), and properties that hold at any size — determinism, every hit of the raycast
+lies on its pixel's ray at the TSDF's zero crossing, voxels and weights stay in range, untouched space stays
+untouched, the brick marks are conservative, and the trajectory follows the synthetic camera.
+"""
+import numpy as np
+import pytest
+
+from oracle import kf_ref
+from slambench_amd import native, synth
+from slambench_amd.config import KFusionConfig, TUM_FR1_DEPTH_INTRINSICS
+from slambench_amd.kfusion import KFusion
+from slambench_amd.metrics import ate
+from tests.util import oracle_config
+
+pytestmark = pytest.mark.gpu
+
+V = 512
+N = 24
+
+
+@pytest.fixture(scope="module")
+def stream():
+    return synth.make_sequence(N, seed=1, intrinsics=TUM_FR1_DEPTH_INTRINSICS, noise=True)
+
+
+@pytest.fixture(scope="module")
+def cfg():
+    return KFusionConfig(input_size=(640, 480), intrinsics=TUM_FR1_DEPTH_INTRINSICS, compute_size_ratio=1,
+                         volume_resolution=(V, V, V))
+
+
+def test_first_frames_match_the_oracle(torch_cuda, cfg, stream):
+    depth, gt, ts = stream
+    kf_ref.set_threads(16)
+    ref = kf_ref.KFusionRef(oracle_config(cfg))
+    kf = KFusion(cfg)
+    for i in range(4):
+        flags = ref.process_frame(depth[i])
+        kf.process_frame(depth[i])
+        st = kf.status(i)
+        assert (st["tracked"], st["integrated"], st["raycasted"]) == (bool(flags & 1), bool(flags & 2), bool(flags & 4))
+    # the pose is still the initial one: identical inputs everywhere, so everything is bit-exact
+    assert np.array_equal(kf.pose, ref.pose)
+    assert np.array_equal(kf.download(native.BUF_FLOAT_DEPTH), ref.float_depth())
+    vol = kf.download(native.BUF_VOLUME)
+    assert np.array_equal(vol, ref.volume())
+    assert np.array_equal(kf.download(native.BUF_MODEL_VERTEX)[..., :3], ref.model_vertex())
+    hit = ref.model_normal()[..., 0] != -2
+    assert hit.mean() > 0.8
+    assert np.array_equal(kf.download(native.BUF_MODEL_NORMAL)[..., :3][hit], ref.model_normal()[hit])
+    del vol
+    for i in range(4, 8):
+        flags = ref.process_frame(depth[i])
+        kf.process_frame(depth[i])
+        st = kf.status(i)
+        assert (st["tracked"], st["integrated"], st["raycasted"]) == (bool(flags & 1), bool(flags & 2), bool(flags & 4))
+        assert st["tracked"]
+        assert np.linalg.norm(st["pose"][:3, 3] - ref.pose[:3, 3]) < 1e-5           # summation order only
+    ref.close()
+    kf.close()
+
+
+def _trilinear(vol, dim, p):
+    """TSDF value at metric points p [n, 3] with the reference's interpolation (float64 is enough here)."""
+    res = np.array(vol.shape[2::-1], np.float64)            # X, Y, Z
+    scaled = p * (res / np.asarray(dim, np.float64)) - 0.5
+    base = np.floor(scaled).astype(np.int64)
+    f = scaled - base
+    out = np.zeros(len(p))
+    for dz in (0, 1):
+        for dy in (0, 1):
+            for dx in (0, 1):
+                ix = np.clip(base[:, 0] + dx, 0, vol.shape[2] - 1)
+                iy = np.clip(base[:, 1] + dy, 0, vol.shape[1] - 1)
+                iz = np.clip(base[:, 2] + dz, 0, vol.shape[0] - 1)
+                w = (f[:, 0] if dx else 1 - f[:, 0]) * (f[:, 1] if dy else 1 - f[:, 1]) * (f[:, 2] if dz else 1 - f[:, 2])
+                out += w * vol[iz, iy, ix, 0]
+    return out / 32766.0
+
+
+def test_properties_at_full_size(torch_cuda, cfg, stream):
+    torch = torch_cuda
+    depth, gt, ts = stream
+    runs = []
+    for rep in range(2):
+        kf = KFusion(cfg)
+        for i in range(N):
+            kf.process_frame(depth[i])
+        runs.append((kf, kf.trajectory()))
+    (kf, traj), (kf2, traj2) = runs
+    # determinism: same binary, same inputs, same bits
+    assert np.array_equal(traj, traj2)
+    vol_t = torch.from_numpy(kf.download(native.BUF_VOLUME)).cuda()
+    assert torch.equal(vol_t, torch.from_numpy(kf2.download(native.BUF_VOLUME)).cuda())
+    kf2.close()
+
+    # the trajectory follows the synthetic camera (ground truth known exactly); all frames after start-up tracked
+    assert all(kf.status(f)["tracked"] for f in range(4, N))
+    assert ate(traj, gt, ts, ts)["rmse"] < 0.01
+
+    # voxel ranges, and most of the 8 m cube was never touched
+    tsdf, weight = vol_t[..., 0], vol_t[..., 1]
+    assert int(tsdf.min()) >= -32766 and int(tsdf.max()) <= 32766
+    assert int(weight.min()) >= 0 and int(weight.max()) <= 100
+    untouched = (weight == 0)
+    assert bool((tsdf[untouched] == 32766).all())
+    assert 0.5 < float(untouched.float().mean()) < 0.999
+
+    # brick marks: a marked brick has no voxel below 26300 in it or in the one-voxel rim past it
+    marks = torch.from_numpy(kf.download(native.BUF_BRICK_MARKS)).cuda()
+    low = (tsdf < 26300).float()[None, None]
+    # a voxel at index i belongs to the rim of the brick before it when i % 8 == 0: pool windows of 9 with stride 8
+    padded = torch.nn.functional.pad(low, (0, 1, 0, 1, 0, 1))
+    any_low = torch.nn.functional.max_pool3d(padded, kernel_size=9, stride=8)[0, 0] > 0
+    assert any_low.shape == marks.shape
+    violations = int((any_low & (marks != 0)).sum())
+    assert violations == 0, violations
+    cleared = float((marks == 0).float().mean())       # the band around the seen surfaces: a thin shell of the cube
+    assert 0.001 < cleared < 0.5, cleared
+
+    # raycast: hits lie on their pixel's ray at the zero crossing, normals have unit length
+    vertex = kf.download(native.BUF_MODEL_VERTEX)[..., :3].astype(np.float64)
+    normal = kf.download(native.BUF_MODEL_NORMAL)[..., :3].astype(np.float64)
+    ray_t = kf.download(native.BUF_RAY_T).astype(np.float64)
+    hit = normal[..., 0] != -2
+    assert hit.mean() > 0.8
+    assert (ray_t[hit] > 0).all()
+    np.testing.assert_allclose(np.linalg.norm(normal[hit], axis=-1), 1.0, atol=1e-5)
+    pose = traj[N - 1].astype(np.float64)                               # the last raycast used the last pose
+    fx, fy, cx, cy = TUM_FR1_DEPTH_INTRINSICS
+    ys, xs = np.nonzero(hit)
+    pick = np.random.default_rng(0).choice(len(ys), 4000, replace=False)
+    ys, xs = ys[pick], xs[pick]
+    dirs = np.stack([(xs - cx) / fx, (ys - cy) / fy, np.ones(len(xs))], axis=-1) @ pose[:3, :3].T
+    want = pose[:3, 3] + dirs * ray_t[ys, xs, None]
+    np.testing.assert_allclose(vertex[ys, xs], want, atol=5e-5)
+    vol = vol_t.cpu().numpy()
+    f = _trilinear(vol, cfg.volume_size, vertex[ys, xs])
+    # the crossing is interpolated linearly between the last two samples: a fine step (1/64 m) apart on smooth
+    # surfaces, a coarse one (0.075 m) where the ray runs into an edge, so a few percent are farther off
+    af = np.abs(f)
+    assert np.median(af) < 0.01 and np.percentile(af, 95) < 0.1, (np.median(af), np.percentile(af, [90, 95, 99]))
+    kf.close()
