@@ -75,6 +75,8 @@ struct kfh_context {
     float *d_scaled[3] = {nullptr, nullptr, nullptr};
     float *set_float_depth[2] = {nullptr, nullptr};
     float *set_scaled[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
+    float *d_tile_max = nullptr;           // largest depth per preprocessing tile of the current set
+    float *set_tile_max[2] = {nullptr, nullptr};
     int next_set = 0;
     hipStream_t pre_stream = nullptr;
     hipEvent_t ev_pre_done = nullptr;      // recorded on pre_stream after each preprocessing launch
@@ -146,7 +148,7 @@ void free_all(kfh_context *c) {
         if (c->h_depth_pinned[i]) (void)hipHostFree(c->h_depth_pinned[i]);
         if (c->ev_slot_free[i]) (void)hipEventDestroy(c->ev_slot_free[i]);
     }
-    void *bufs[] = {c->d_depth_in[0], c->d_depth_in[1], c->set_float_depth[0], c->set_float_depth[1], c->set_scaled[0][0],
+    void *bufs[] = {c->set_tile_max[0], c->set_tile_max[1], c->d_depth_in[0], c->d_depth_in[1], c->set_float_depth[0], c->set_float_depth[1], c->set_scaled[0][0],
                     c->set_scaled[0][1], c->set_scaled[0][2], c->set_scaled[1][0], c->set_scaled[1][1],
                     c->set_scaled[1][2],
                     c->d_in_vertex[0], c->d_in_vertex[1], c->d_in_vertex[2], c->d_in_normal[0],
@@ -181,6 +183,7 @@ hipError_t ensure_pre_done(kfh_context *c) {
 void select_set(kfh_context *c, int set) {
     c->cur_set = set;
     c->d_float_depth = c->set_float_depth[set];
+    c->d_tile_max = c->set_tile_max[set];
     for (int l = 0; l < 3; ++l) c->d_scaled[l] = c->set_scaled[set][l];
 }
 
@@ -284,6 +287,7 @@ int kfh_create(const kfh_config *cfg, kfh_context **out) {
     for (int i = 0; i < 2 && e == hipSuccess; ++i) {
         e = hipEventCreateWithFlags(&c->ev_set_free[i], hipEventDisableTiming);
         if (e == hipSuccess) e = dev_alloc(&c->set_float_depth[i], npix);
+        if (e == hipSuccess) e = dev_alloc(&c->set_tile_max[i], depth_tile_count(c->w, c->h));
     }
     // Opt-in: on MI355X the cross-stream event waits this needs cost more per frame (about 20 us measured)
     // than the 13 us preprocessing launch they hide, so a single stream is the default.
@@ -398,7 +402,7 @@ int kfh_preprocess(kfh_context *c) {
     // the depth pyramid of tracking (halfSampleRobustImageKernel twice) is produced by the same launch
     KFH_HIP(launch_preprocess(c->d_float_depth, c->d_scaled[0], c->w, c->h, c->d_depth_cur, true,
                               c->cfg.input_width, c->cfg.compute_size_ratio, c->cfg.depth_divisor, c->d_scaled[1],
-                              c->d_scaled[2], E_DELTA * 3, ps));
+                              c->d_scaled[2], E_DELTA * 3, c->d_tile_max, ps));
     c->depth_version++;
     for (int i = 0; i < 2; ++i)      // a staging slot is free again once this launch has read it
         if (c->d_depth_cur == c->d_depth_in[i]) {
@@ -460,6 +464,12 @@ int kfh_track(kfh_context *c) {
     return KFH_OK;
 }
 
+// The per-tile depth maxima let the integration drop boxes behind the seen surface (KFH_NO_DEPTH_CULL: off).
+static const float *tile_max_for_integrate(const kfh_context *c) {
+    static const bool off = std::getenv("KFH_NO_DEPTH_CULL") != nullptr;
+    return off ? nullptr : c->d_tile_max;
+}
+
 int kfh_integrate(kfh_context *c) {
     KFH_REQUIRE(c != nullptr, "context is NULL");
     KFH_HIP(ensure_pre_done(c));
@@ -469,7 +479,7 @@ int kfh_integrate(kfh_context *c) {
         KFH_HIP(launch_integrate(c->d_volume, c->cfg.vol_res, c->cfg.vol_dim, c->zs0, c->zs1, src, c->w, c->h,
                                  &c->d_ctrl->inv_pose, camera_matrix(c->k[0], c->k[1], c->k[2], c->k[3]),
                                  c->cfg.mu, MAX_WEIGHT, &c->d_ctrl->integrate_gate, c->d_integrate_boxes,
-                                 &c->d_ctrl->integrate_box_count, c->d_bricks, c->stream));
+                                 &c->d_ctrl->integrate_box_count, c->d_bricks, tile_max_for_integrate(c), c->stream));
     }
     if (timed_frame(c)) {
         KFH_HIP(hipEventRecord(c->ev[c->frame % KFH_TIMING_RING][3], c->stream));
@@ -783,7 +793,7 @@ int kfh_debug_integrate_stats(kfh_context *c, unsigned long long *h_out, size_t 
     hipError_t e = launch_integrate(c->d_volume, c->cfg.vol_res, c->cfg.vol_dim, c->zs0, c->zs1, src, c->w, c->h,
                                     &c->d_ctrl->inv_pose, camera_matrix(c->k[0], c->k[1], c->k[2], c->k[3]),
                                     c->cfg.mu, MAX_WEIGHT, nullptr, c->d_integrate_boxes,
-                                    &c->d_ctrl->integrate_box_count, c->d_bricks, c->stream);
+                                    &c->d_ctrl->integrate_box_count, c->d_bricks, tile_max_for_integrate(c), c->stream);
     set_integrate_debug(nullptr);
     if (e == hipSuccess) e = hipMemcpyAsync(h_out + n_values - 1, &c->d_ctrl->integrate_box_count, sizeof(unsigned),
                                             hipMemcpyDeviceToHost, c->stream);
@@ -843,13 +853,13 @@ int kfh_k_preprocess(float *d_raw, float *d_filtered, int ow, int oh, const uint
     KFH_REQUIRE(iw % ow == 0 && ih % oh == 0 && iw / ow == ih / oh, "input size must be an integer multiple of the output size");
     KFH_REQUIRE(depth_divisor > 0.f, "depth_divisor must be positive");
     KFH_HIP(launch_preprocess(d_raw, d_filtered, ow, oh, d_in, true, iw, iw / ow, depth_divisor, nullptr, nullptr, 0.f,
-                              static_cast<hipStream_t>(stream)));
+                              nullptr, static_cast<hipStream_t>(stream)));
     return KFH_OK;
 }
 
 int kfh_k_bilateral(float *d_out, const float *d_in, int w, int h, void *stream) {
     KFH_REQUIRE(d_out && d_in && w > 0 && h > 0, "bad argument");
-    KFH_HIP(launch_preprocess(nullptr, d_out, w, h, d_in, false, w, 1, 1.0f, nullptr, nullptr, 0.f,
+    KFH_HIP(launch_preprocess(nullptr, d_out, w, h, d_in, false, w, 1, 1.0f, nullptr, nullptr, 0.f, nullptr,
                               static_cast<hipStream_t>(stream)));
     return KFH_OK;
 }
@@ -924,7 +934,7 @@ int kfh_k_integrate(void *d_volume, const int32_t res[3], const float dim[3], in
     if (e == hipSuccess) e = hipMemsetAsync(d_count, 0, sizeof(unsigned), s);
     if (e == hipSuccess)
         e = launch_integrate(static_cast<short2 *>(d_volume), res, dim, z0, z1, d_depth, w, h, d_inv, Km, mu,
-                             maxweight, nullptr, reinterpret_cast<unsigned *>(scratch + 512), d_count, nullptr, s);
+                             maxweight, nullptr, reinterpret_cast<unsigned *>(scratch + 512), d_count, nullptr, nullptr, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     (void)hipFree(scratch);
     KFH_HIP(e);

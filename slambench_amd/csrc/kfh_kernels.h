@@ -115,7 +115,9 @@ struct FinishArgs {
 // level1 / level2 (both or neither): also write the two robust half-samplings of the filtered image
 hipError_t launch_preprocess(float *raw, float *filtered, int ow, int oh, const void *in, bool in_is_u16,
                              int iw, int ratio, float divisor, float *level1, float *level2, float pyramid_e_d,
-                             hipStream_t s);
+                             float *tile_max, hipStream_t s);
+// floats of the per-tile depth maxima launch_preprocess writes (tile_max != null) and launch_integrate reads
+size_t depth_tile_count(int w, int h);
 hipError_t launch_half_sample(float *out, const float *in, int iw, int ih, float e_d, hipStream_t s);
 hipError_t launch_vertex_normal(float4 *vertex, float4 *normal, const float *depth, int w, int h, float fx,
                                 float fy, float cx, float cy, hipStream_t s);
@@ -142,7 +144,7 @@ size_t integrate_box_list_bytes(const int res[3], int z1);
 hipError_t launch_integrate(short2 *vol, const int res[3], const float dim[3], int z0, int z1,
                             const float *depth, int w, int h, const Mat4 *inv_track, Mat4 K, float mu,
                             float maxweight, const int *gate, unsigned *boxes, unsigned *box_count,
-                            unsigned char *bricks, hipStream_t s);
+                            unsigned char *bricks, const float *tile_max, hipStream_t s);
 // One byte per 8^3-voxel brick ("nothing a coarse raycast step could notice in here"): integrate clears marks,
 // raycast skips marked bricks.  Optional (null) in both launches; whole volumes only.
 inline size_t brick_mark_bytes(const int res[3]) {

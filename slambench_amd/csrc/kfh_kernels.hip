@@ -46,12 +46,14 @@ __global__ __launch_bounds__(256) void k_preprocess(float *__restrict__ raw, flo
                                                     int ow, int oh, const void *__restrict__ in, int iw,
                                                     int ratio, float divisor, BilateralConst bc,
                                                     float *__restrict__ level1, float *__restrict__ level2,
-                                                    float pyramid_e_d) {
+                                                    float pyramid_e_d, float *__restrict__ tile_max) {
     __shared__ float tile[PRE_LH][PRE_LW];
     __shared__ float f0[PRE_TY][PRE_TX];
     __shared__ float f1[PRE_TY / 2][PRE_TX / 2];
+    __shared__ float wave_max[4];
     const int tid = threadIdx.x;
     const int bx = blockIdx.x * PRE_TX, by = blockIdx.y * PRE_TY;
+    float vmax = 0.f;
     for (int idx = tid; idx < PRE_LW * PRE_LH; idx += 256) {
         const int ly = idx / PRE_LW, lx = idx - ly * PRE_LW;
         const int gx = min(max(bx + lx - PRE_R, 0), ow - 1);
@@ -64,8 +66,17 @@ __global__ __launch_bounds__(256) void k_preprocess(float *__restrict__ raw, flo
             v = static_cast<const float *>(in)[gx + gy * ow];
         }
         tile[ly][lx] = v;
+        vmax = fmaxf(vmax, v);
+    }
+    if (tile_max) {
+        // largest depth of the tile and its apron: lets the integration skip boxes that lie wholly behind the
+        // surface seen through them (every raw or filtered value the tile can produce is at most this)
+        for (int m = 32; m >= 1; m >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, m, 64));
+        if ((tid & 63) == 0) wave_max[tid >> 6] = vmax;
     }
     __syncthreads();
+    if (tile_max && tid == 0)
+        tile_max[blockIdx.y * gridDim.x + blockIdx.x] = fmaxf(fmaxf(wave_max[0], wave_max[1]), fmaxf(wave_max[2], wave_max[3]));
     const int tx = tid & (PRE_TX - 1), ty = tid >> 5;
     const int x = bx + tx, y = by + ty;
     const bool inside = x < ow && y < oh;
@@ -113,6 +124,8 @@ __global__ __launch_bounds__(256) void k_preprocess(float *__restrict__ raw, flo
     }
 }
 
+size_t depth_tile_count(int w, int h) { return (size_t)((w + PRE_TX - 1) / PRE_TX) * ((h + PRE_TY - 1) / PRE_TY); }
+
 static BilateralConst bilateral_const() {
     BilateralConst bc;
     const float delta = 4.0f, e_d = 0.1f;
@@ -126,20 +139,20 @@ static BilateralConst bilateral_const() {
 
 hipError_t launch_preprocess(float *raw, float *filtered, int ow, int oh, const void *in, bool in_is_u16,
                              int iw, int ratio, float divisor, float *level1, float *level2, float pyramid_e_d,
-                             hipStream_t s) {
+                             float *tile_max, hipStream_t s) {
     const dim3 grid((ow + PRE_TX - 1) / PRE_TX, (oh + PRE_TY - 1) / PRE_TY);
     const BilateralConst bc = bilateral_const();
     const bool pyramid = level1 != nullptr && level2 != nullptr;
     if (pyramid && (!filtered || !in_is_u16 || ow % 4 != 0 || oh % 4 != 0)) return hipErrorInvalidValue;
     if (pyramid)
         hipLaunchKernelGGL((k_preprocess<true, true>), grid, dim3(256), 0, s, raw, filtered, ow, oh, in, iw, ratio,
-                           divisor, bc, level1, level2, pyramid_e_d);
+                           divisor, bc, level1, level2, pyramid_e_d, tile_max);
     else if (in_is_u16)
         hipLaunchKernelGGL((k_preprocess<true, false>), grid, dim3(256), 0, s, raw, filtered, ow, oh, in, iw, ratio,
-                           divisor, bc, level1, level2, pyramid_e_d);
+                           divisor, bc, level1, level2, pyramid_e_d, tile_max);
     else
         hipLaunchKernelGGL((k_preprocess<false, false>), grid, dim3(256), 0, s, raw, filtered, ow, oh, in, iw, ratio,
-                           divisor, bc, level1, level2, pyramid_e_d);
+                           divisor, bc, level1, level2, pyramid_e_d, tile_max);
     return hipGetLastError();
 }
 
@@ -1467,6 +1480,8 @@ struct IntegrateArgs {
     unsigned *box_count;
     unsigned char *bricks;      // per 8^3 brick: 1 while no voxel of the brick (plus one voxel past it) went
     int bgx, bgy;               //   below RAY_COARSE_SAFE since the last reset; may be null
+    const float *tile_max;      // largest depth per preprocessing tile (PRE_TX x PRE_TY pixels, apron included); may be null
+    int tiles_x, tiles_y;
     unsigned long long *dbg;
 };
 
@@ -1475,7 +1490,8 @@ struct IntegrateArgs {
 // eight corners of the grown box fail the same half-space, no voxel of the box can pass it (the two voxels
 // of slack are far more than the drift of the incrementally accumulated positions).
 __device__ inline bool box_misses_frustum(const IntegrateArgs &a, const Mat4 &invTrack, int bx, int by, int zc0,
-                                          int zc1) {
+                                          int zc1, const float *tile_max_lds, const float *coarse_max_lds,
+                                          bool depth_test) {
     const float wmax = (float)(a.w - 1), hmax = (float)(a.h - 1);
     const float vx = a.dimx / (float)a.sx, vy = a.dimy / (float)a.sy, vz = a.dimz / (float)a.sz;
     const float bx0 = ((float)(bx * 64 - 2) + 0.5f) * vx;
@@ -1489,6 +1505,8 @@ __device__ inline bool box_misses_frustum(const IntegrateArgs &a, const Mat4 &in
     const f3 ey = rotate(invTrack, mk3(0.f, by1 - by0, 0.f));
     const f3 ez = rotate(invTrack, mk3(0.f, 0.f, bz1 - bz0));
     bool behind = true, left = true, right = true, up = true, down = true;
+    bool all_front = true;
+    float zmin = 3.0e38f, pxmin = 3.0e38f, pxmax = -3.0e38f, pymin = 3.0e38f, pymax = -3.0e38f;
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
         f3 P = c0;
@@ -1502,15 +1520,91 @@ __device__ inline bool box_misses_frustum(const IntegrateArgs &a, const Mat4 &in
         right = right && (cxp > (wmax + 1.5f) * P.z);
         up = up && (cyp < -1.5f * P.z);
         down = down && (cyp > (hmax + 1.5f) * P.z);
+        all_front = all_front && (P.z > 0.01f);
+        zmin = fminf(zmin, P.z);
+        const float px = cxp / P.z, py = cyp / P.z;
+        pxmin = fminf(pxmin, px); pxmax = fmaxf(pxmax, px);
+        pymin = fminf(pymin, py); pymax = fmaxf(pymax, py);
     }
-    return behind || left || right || up || down;
+    if (behind || left || right || up || down) return true;
+    // Behind the surface: a voxel is left untouched when the depth seen through its pixel is at least mu in
+    // front of it.  With every corner of the grown box in front of the camera the box projects inside the
+    // bounding rectangle of its corners; if even the largest depth of the tiles under that rectangle (4 pixels
+    // of slack) ends mu before the nearest corner, no voxel of the box can be updated.
+    if (depth_test && all_front) {
+        const int x0 = max((int)fmaxf(floorf(pxmin), -8.f) - 4, 0), x1 = min((int)fminf(ceilf(pxmax), wmax + 8.f) + 4, a.w - 1);
+        const int y0 = max((int)fmaxf(floorf(pymin), -8.f) - 4, 0), y1 = min((int)fminf(ceilf(pymax), hmax + 8.f) + 4, a.h - 1);
+        const int tx0 = x0 / PRE_TX, tx1 = x1 / PRE_TX, ty0 = y0 / PRE_TY, ty1 = y1 / PRE_TY;
+        // One thread reads the maxima under its rectangle from the block's LDS copies: tile by tile for a small
+        // rectangle, otherwise from the 4 x 4-tile cells that cover it.  A single loop over the cells, four
+        // reads in flight: the lanes of a wavefront have rectangles of different shapes, and nested loops would
+        // run for the largest width times the largest height among them.  A box near the camera covers much
+        // of the image and is rarely behind everything seen there: it is not tested.
+        if (x0 <= x1 && y0 <= y1) {
+            float maxd = 3.0e38f;
+            const bool fine_cells = (tx1 - tx0 + 1) * (ty1 - ty0 + 1) <= 16;
+            const int ox = fine_cells ? tx0 : tx0 >> 2, oy = fine_cells ? ty0 : ty0 >> 2;
+            const int nx = (fine_cells ? tx1 : tx1 >> 2) - ox + 1, ny = (fine_cells ? ty1 : ty1 >> 2) - oy + 1;
+            const int pitch = fine_cells ? a.tiles_x : (a.tiles_x + 3) >> 2;
+            const float *cells = fine_cells ? tile_max_lds : coarse_max_lds;
+            const int n = nx * ny;
+            if (n <= 24) {
+                maxd = 0.f;
+                const float inv_nx = 1.0f / (float)nx;
+                for (int i = 0; i < n; i += 4) {
+                    float v[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int j = min(i + k, n - 1);
+                        const int jy = (int)(((float)j + 0.5f) * inv_nx), jx = j - jy * nx;
+                        v[k] = cells[(oy + jy) * pitch + ox + jx];
+                    }
+                    maxd = fmaxf(fmaxf(maxd, fmaxf(v[0], v[1])), fmaxf(v[2], v[3]));
+                }
+            }
+            if (zmin - maxd > a.mu + 1e-3f) return true;      // includes "no valid depth at all" for boxes past mu
+        }
+    }
+    return false;
 }
 
 // First launch: one thread per box decides whether the box can touch the frustum and appends the survivors
 // to the list (typically a few percent of the volume).  The work launch then only runs on those, instead
 // of dispatching a workgroup per box of the whole volume.
+constexpr int KFH_PLAN_TILES_PER_THREAD = 8;
+constexpr int KFH_PLAN_MAX_TILES = 256 * KFH_PLAN_TILES_PER_THREAD;     // depth tiles a plan block holds in LDS (640 x 480: 1200)
 __global__ __launch_bounds__(256) void k_integrate_plan(IntegrateArgs a) {
-    if (a.gate && *a.gate == 0) return;
+    __shared__ float tile_max_lds[KFH_PLAN_MAX_TILES];
+    __shared__ float coarse_max_lds[KFH_PLAN_MAX_TILES / 16 + 64];     // maxima of 4 x 4 tiles
+    // everything the block reads from memory is requested at once, the gate included
+    const int ntiles = a.tiles_x * a.tiles_y;
+    const bool depth_test = a.tile_max != nullptr && ntiles <= KFH_PLAN_MAX_TILES && a.tiles_x <= 64;
+    float tm[KFH_PLAN_TILES_PER_THREAD];
+#pragma unroll
+    for (int k = 0; k < KFH_PLAN_TILES_PER_THREAD; ++k)
+        tm[k] = depth_test ? a.tile_max[min((int)threadIdx.x + 256 * k, ntiles - 1)] : 0.f;
+    const Mat4 inv_track = *a.inv_track;
+    const int gate = a.gate ? *a.gate : 1;
+    if (gate == 0) return;
+    if (depth_test) {
+#pragma unroll
+        for (int k = 0; k < KFH_PLAN_TILES_PER_THREAD; ++k) tile_max_lds[threadIdx.x + 256 * k] = tm[k];
+        __syncthreads();
+        // four threads per cell, one tile row each, combined inside the quad
+        const int cw = (a.tiles_x + 3) >> 2, ch = (a.tiles_y + 3) >> 2;
+        for (int i = threadIdx.x; i < ((cw * ch * 4 + 255) & ~255); i += 256) {
+            const int cell = min(i >> 2, cw * ch - 1), r = i & 3;
+            const int cy = cell / cw, cx = cell - cy * cw;
+            const int ty = min(cy * 4 + r, a.tiles_y - 1);
+            float m = 0.f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) m = fmaxf(m, tile_max_lds[ty * a.tiles_x + min(cx * 4 + q, a.tiles_x - 1)]);
+            m = fmaxf(m, __shfl_xor(m, 1, 64));
+            m = fmaxf(m, __shfl_xor(m, 2, 64));
+            if (r == 0 && (i >> 2) < cw * ch) coarse_max_lds[cell] = m;
+        }
+        __syncthreads();
+    }
     const int id = blockIdx.x * blockDim.x + threadIdx.x;
     const int nbox = a.gx * a.gy * a.gz;
     bool keep = false;
@@ -1520,7 +1614,7 @@ __global__ __launch_bounds__(256) void k_integrate_plan(IntegrateArgs a) {
         by = (id / a.gx) % a.gy;
         bz = id / (a.gx * a.gy);
         const int zc0 = max(a.z0, bz * a.zchunk), zc1 = min(a.z1, (bz + 1) * a.zchunk);
-        keep = zc0 < zc1 && !box_misses_frustum(a, *a.inv_track, bx, by, zc0, zc1);
+        keep = zc0 < zc1 && !box_misses_frustum(a, inv_track, bx, by, zc0, zc1, tile_max_lds, coarse_max_lds, depth_test);
     }
     const unsigned long long m = __ballot(keep);
     if (m) {
@@ -1681,15 +1775,22 @@ __global__ __launch_bounds__(256) void k_integrate(IntegrateArgs a) {
 static unsigned long long *g_integrate_debug = nullptr;   // diagnostics buffer, [box][4 wavefronts][4]
 void set_integrate_debug(unsigned long long *d_buffer) { g_integrate_debug = d_buffer; }
 
+// z extent of a box (a multiple of INTEGRATE_UNROLL); KFH_INTEGRATE_ZCHUNK overrides it for experiments
+static int integrate_zchunk(int z1) {
+    static const int forced = std::getenv("KFH_INTEGRATE_ZCHUNK") ? std::atoi(std::getenv("KFH_INTEGRATE_ZCHUNK")) : 0;
+    if (forced >= INTEGRATE_UNROLL && forced % INTEGRATE_UNROLL == 0) return forced;
+    return z1 <= 512 ? 16 : 64;      // measured at 512^3: 16 -> 35 us per integration, 32 -> 40 us, 64 -> 54 us
+}
+
 size_t integrate_box_list_bytes(const int res[3], int z1) {
-    const int zchunk = z1 <= 512 ? 32 : 64;
+    const int zchunk = integrate_zchunk(z1);
     return (size_t)((res[0] + 63) / 64) * ((res[1] + 3) / 4) * ((z1 + zchunk - 1) / zchunk) * sizeof(unsigned);
 }
 
 hipError_t launch_integrate(short2 *vol, const int res[3], const float dim[3], int z0, int z1,
                             const float *depth, int w, int h, const Mat4 *inv_track, Mat4 K, float mu,
                             float maxweight, const int *gate, unsigned *boxes, unsigned *box_count,
-                            unsigned char *bricks, hipStream_t s) {
+                            unsigned char *bricks, const float *tile_max, hipStream_t s) {
     // Short z chunks: boxes that miss the camera frustum never reach the work launch, the others replay the
     // column prefix (a few packed adds per step) and then march only zchunk steps, so no wavefront runs long.
     IntegrateArgs a;
@@ -1699,10 +1800,11 @@ hipError_t launch_integrate(short2 *vol, const int res[3], const float dim[3], i
     a.z0 = z0; a.z1 = z1;
     a.depth = depth; a.w = w; a.h = h;
     a.inv_track = inv_track; a.K = K; a.mu = mu; a.maxweight = maxweight; a.gate = gate;
-    a.zchunk = z1 <= 512 ? 32 : 64;
+    a.zchunk = integrate_zchunk(z1);
     a.gx = (res[0] + 63) / 64; a.gy = (res[1] + 3) / 4; a.gz = (z1 + a.zchunk - 1) / a.zchunk;
     a.boxes = boxes; a.box_count = box_count;
     a.bricks = bricks; a.bgx = (res[0] + 7) / 8; a.bgy = (res[1] + 7) / 8;
+    a.tile_max = tile_max; a.tiles_x = (w + PRE_TX - 1) / PRE_TX; a.tiles_y = (h + PRE_TY - 1) / PRE_TY;
     a.dbg = g_integrate_debug;
     if (a.gx > 256 || a.gy > 4096 || a.gz > 4096) return hipErrorInvalidValue;   // packed box id
     const int nbox = a.gx * a.gy * a.gz;
