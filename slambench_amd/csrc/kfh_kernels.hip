@@ -2109,11 +2109,16 @@ __global__ __launch_bounds__(256, 5) void k_raycast_march(float4 *__restrict__ v
     }
 
     int rounds = 0;
-    unsigned dbg_samples = 0, dbg_skipped = 0;
+    unsigned dbg_samples = 0, dbg_skipped = 0, dbg_heavy_rounds = 0;
+    unsigned long long dbg_heavy_ticks = 0, dbg_loop_t0 = 0, dbg_loop_t1 = 0;
+    if (dbg) dbg_loop_t0 = __builtin_amdgcn_s_memrealtime();
     while (true) {
         const unsigned long long alive = __ballot(marching);
         if (alive == 0 || __popcll(alive) <= RAY_FEW || rounds == max_rounds) break;
         ++rounds;
+        bool dbg_round_heavy = false;
+        unsigned long long dbg_round_t0 = 0;
+        if (dbg) dbg_round_t0 = __builtin_amdgcn_s_memrealtime();
         if (marching) {
             const float stepsize = fine ? step : largestep;
             float tk[RAY_BATCH], fk[RAY_BATCH];
@@ -2173,6 +2178,7 @@ __global__ __launch_bounds__(256, 5) void k_raycast_march(float4 *__restrict__ v
                     dbg_skipped += skip[k] ? 1 : 0;
                 }
             }
+            dbg_round_heavy = !(skip[0] && skip[1] && skip[2] && skip[3]);
             // The samples are consumed in order; written with selects instead of branches (a lane that has met
             // its event stops being `active`), so the four steps cost a few compares each.
             bool active = true;
@@ -2193,7 +2199,12 @@ __global__ __launch_bounds__(256, 5) void k_raycast_march(float4 *__restrict__ v
             }
             if (active) t = tk[RAY_BATCH - 1] + stepsize;
         }
+        if (dbg && __ballot(dbg_round_heavy)) {
+            dbg_heavy_rounds += 1;
+            dbg_heavy_ticks += __builtin_amdgcn_s_memrealtime() - dbg_round_t0;
+        }
     }
+    if (dbg) dbg_loop_t1 = __builtin_amdgcn_s_memrealtime();
 
     // rays still marching go to the second pass
     const unsigned long long left = __ballot(marching);
@@ -2218,8 +2229,11 @@ __global__ __launch_bounds__(256, 5) void k_raycast_march(float4 *__restrict__ v
         unsigned long long *d = dbg + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave) * 4;
         d[0] = dbg_t0;
         d[1] = __builtin_amdgcn_s_memrealtime();
-        d[2] = rounds;
-        d[3] = __popcll(left);
+        // rounds | rounds with voxel fetches << 8 | their ticks << 16;  rays left | ticks before the loop << 8 |
+        // ticks after it << 20
+        d[2] = (unsigned long long)rounds | ((unsigned long long)dbg_heavy_rounds << 8) | ((dbg_heavy_ticks & 0xFFFFull) << 16);
+        d[3] = (unsigned long long)__popcll(left) | (((dbg_loop_t0 - dbg_t0) & 0xFFFull) << 8) |
+               (((d[1] - dbg_loop_t1) & 0xFFFull) << 20);
     }
     if (dbg) {      // lane sums of samples taken / skipped by brick marks, packed into the record's upper halves
         unsigned long long a = dbg_samples, b = dbg_skipped;

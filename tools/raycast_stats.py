@@ -23,8 +23,10 @@ for rep in range(2):
     native.check(L.kfh_debug_raycast_stats(kf._ctx, buf.ctypes.data_as(C.c_void_p)))
 st = buf[:nb * 16].reshape(nb * 4, 4).astype(np.int64)
 samples, skipped = (st[:, 2] >> 32).sum(), (st[:, 3] >> 32).sum()
-st[:, 2] &= 0xFFFFFFFF
-st[:, 3] &= 0xFFFFFFFF
+heavy_rounds, heavy_us = (st[:, 2] >> 8) & 0xFF, ((st[:, 2] >> 16) & 0xFFFF) / 100.0
+pre_us, post_us = ((st[:, 3] >> 8) & 0xFFF) / 100.0, ((st[:, 3] >> 20) & 0xFFF) / 100.0
+st[:, 2] &= 0xFF
+st[:, 3] &= 0xFF
 print('samples in the first pass: %d (%.1f per ray), skipped by brick marks: %d (%.1f%%)' % (samples, samples / (w * h), skipped, 100.0 * skipped / max(samples, 1)))
 print('rays handed to the second pass:', int(buf[-1]) & 0xFFFFFFFF)
 t0 = st[:, 0].min()
@@ -42,3 +44,9 @@ long_ = dur > np.percentile(dur, 95)
 print("slowest 5%%: batches mean %.1f, tail mean %.1f, us per round %.2f" % (
     st[long_, 2].mean(), st[long_, 3].mean(), (dur[long_] / (st[long_, 2] + st[long_, 3]).clip(1)).mean()))
 print("all: us per round %.2f" % (dur / (st[:, 2] + st[:, 3]).clip(1)).mean())
+print("rounds with voxel fetches per wave 10/50/90:", np.percentile(heavy_rounds, [10, 50, 90]), "their time us 10/50/90:", np.round(np.percentile(heavy_us, [10, 50, 90]), 1))
+light = st[:, 2] - heavy_rounds
+print("mark-only rounds per wave 10/50/90:", np.percentile(light, [10, 50, 90]))
+print("time before the loop us 10/50/90:", np.round(np.percentile(pre_us, [10, 50, 90]), 2), "after it:", np.round(np.percentile(post_us, [10, 50, 90]), 2))
+print("sums over waves (us): total %.0f, heavy rounds %.0f, before %.0f, after %.0f, rest (mark-only rounds) %.0f" % (
+    dur.sum(), heavy_us.sum(), pre_us.sum(), post_us.sum(), dur.sum() - heavy_us.sum() - pre_us.sum() - post_us.sum()))
