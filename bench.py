@@ -38,6 +38,9 @@ def parse_args():
     ap.add_argument("--cpu-threads", type=int, default=16)
     ap.add_argument("--cpu-frames-1t", type=int, default=5,
                     help="frames of the additional single-threaded CPU sample (0 = skip)")
+    ap.add_argument("--sequences-per-gpu", type=int, default=1,
+                    help="independent sequences (contexts, one stream each) interleaved on every GPU; the "
+                         "default 1 is the benchmark, more measures how many sweep points one GPU can carry")
     ap.add_argument("--host-frames", action="store_true",
                     help="also time the stream with frames handed over in host memory (one H2D copy per frame); "
                          "reported as pcie_inclusive_frames_per_s, never as value")
@@ -119,6 +122,25 @@ def main():
         kf = KFusion(cfg)
         step = kf.process_frame
     kf.set_timing(3)     # two HIP events around the integration phase of every 16th frame, on the pipeline's stream
+    # further independent sequences on the same GPU (replica mode only): own context, own stream, own frames
+    extra = []
+    if a.sequences_per_gpu > 1 and not zslab:
+        for q in range(1, a.sequences_per_gpu):
+            dq, _, _ = synth.make_sequence(n_unique, seed=100 * q + seed, intrinsics=TUM_FR1_DEPTH_INTRINSICS, noise=True)
+            tq = torch.from_numpy(dq.view(np.int16)).cuda()
+            extra.append((KFusion(cfg), tq, [int(tq[i].data_ptr()) for i in range(n_unique)]))
+    if extra:
+        first_step = step
+
+        def step(ptr_index):           # one frame of every sequence, launches interleaved from this one thread
+            first_step(frame_ptrs[ptr_index])
+            for kq, _, ptrs in extra:
+                kq.process_frame(ptrs[ptr_index])
+    else:
+        single_step = step
+
+        def step(ptr_index):
+            single_step(frame_ptrs[ptr_index])
 
     def barrier():
         if world > 1:
@@ -126,13 +148,19 @@ def main():
         torch.cuda.synchronize()
         kf.sync()
 
+    def sync_all():
+        kf.sync()
+        for kq, _, _ in extra:
+            kq.sync()
+
     for i in range(a.warmup):
-        step(frame_ptrs[order[i]])
+        step(order[i])
+    sync_all()
     barrier()
     t0 = time.perf_counter()
     for i in range(a.warmup, total):
-        step(frame_ptrs[order[i]])
-    kf.sync()
+        step(order[i])
+    sync_all()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -187,7 +215,7 @@ def main():
                 traffic = None
         result = {
             "metric": "KFusion frames/s @640x480 512^3 TSDF; integrate GVox/s; ATE delta vs ref",
-            "value": (1 if zslab else world) * a.steps / elapsed,
+            "value": (1 if zslab else world * (1 + len(extra))) * a.steps / elapsed,
             "unit": "frames/s",
             "n_gpus": world,
             "steps": a.steps,
@@ -203,8 +231,8 @@ def main():
                             "integration-rate 2, synthetic room stream (configs[1])" % V,
                 "compute_size": "%dx%d" % cfg.compute_size, "volume": V,
                 "parallelism": ("one sequence, volume in %d z-slabs, raycast segments all-gathered (%s)" % (world, a.backend)
-                                if zslab else "1 sequence per GPU (replicas, no collective)" if world > 1
-                                else "single GPU"),
+                                if zslab else "%d sequence(s) per GPU (replicas, no collective)" % (1 + len(extra))
+                                if (world > 1 or extra) else "single GPU"),
             },
             "integrate_gvox_per_s": (V * V * planes / t_int / 1e9) if integ_ms.size else None,
             "integrate_ms": t_int * 1e3 if integ_ms.size else None,
@@ -252,6 +280,8 @@ def main():
             result["ate_delta_vs_cpu_m"] = abs(a_hip - a_cpu) if a_hip is not None else None
             result["max_position_delta_vs_cpu_m"] = float(d.max()) if d is not None else None
     kf.close()
+    for kq, _, _ in extra:
+        kq.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -16,6 +16,8 @@ ap = argparse.ArgumentParser()
 ap.add_argument("input")
 ap.add_argument("--gpus", default="0")
 ap.add_argument("--grid", nargs="+", required=True, metavar="option=v1,v2,...")
+ap.add_argument("--per-gpu", type=int, default=1,
+                help="processes sharing one GPU at a time (the pipeline is latency-bound: 3-4 sequences fit one MI355X)")
 ap.add_argument("-fl", "--frame-limit", type=int, default=0)
 a = ap.parse_args()
 grid = {}
@@ -27,7 +29,7 @@ if a.input.endswith(".slam"):
     _, _, _, gt, gt_ts = slamfile.read_depth_sequence(a.input)
 points = dse.grid_points(grid)
 results = dse.run_sweep(points, dse.mini_harness_cmd(a.input, frame_limit=a.frame_limit),
-                        [int(g) for g in a.gpus.split(",")], summarise_fn=lambda t: dse.summarise(t, gt, gt_ts))
+                        [int(g) for g in a.gpus.split(",")] * max(1, a.per_gpu), summarise_fn=lambda t: dse.summarise(t, gt, gt_ts))
 keys = list(grid)
 print("\t".join(keys + ["frames", "mean_frame_s", "ate_rmse_m", "gpu", "status"]))
 for r in results:
