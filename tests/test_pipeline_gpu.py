@@ -173,3 +173,30 @@ def test_invalid_config_is_rejected(torch_cuda):
     ctx = C.c_void_p()
     rc = native.lib().kfh_create(C.byref(c), C.byref(ctx))
     assert rc == 1 and not ctx.value
+
+
+def test_degenerate_frames_match_oracle(torch_cuda):
+    """Frames without a single valid pixel, saturated frames and a sudden jump: no fault, the same flags and the
+    same pose as the oracle (a rejected pose is restored exactly, so the comparison is bit-exact there)."""
+    cfg = KFusionConfig(compute_size_ratio=4, volume_resolution=(128, 128, 128))
+    depth, gt, ts = synth.make_sequence(14, seed=4, noise=True)
+    depth = depth.copy()
+    depth[5] = 0                                    # sensor drop-out
+    depth[6] = 65535                                # everything beyond the far plane / volume
+    depth[9] = depth[0][::-1, ::-1]                 # a view the model cannot explain
+    depth[11, :, :320] = 0                          # half of the image missing
+    ref, kf, flags_ref, poses_ref = _run_both(cfg, depth)
+    tracked = []
+    for f in range(14):
+        st = kf.status(f)
+        want = flags_ref[f]
+        assert (st["tracked"], st["integrated"], st["raycasted"]) == (bool(want & 1), bool(want & 2), bool(want & 4)), f
+        assert np.isfinite(st["pose"]).all() and np.isfinite(st["sums"]).all(), f
+        assert np.linalg.norm(st["pose"][:3, 3] - poses_ref[f][:3, 3]) < 1e-4, f
+        tracked.append(st["tracked"])
+    assert not tracked[5] and not tracked[6]        # nothing to track against
+    assert tracked[4] and tracked[8]
+    vol = kf.download(native.BUF_VOLUME)
+    assert np.isfinite(kf.download(native.BUF_MODEL_VERTEX)).all()
+    assert int(vol[..., 1].max()) <= 100 and int(np.abs(vol[..., 0].astype(np.int32)).max()) <= 32766
+    kf.close()
