@@ -1779,7 +1779,8 @@ void set_integrate_debug(unsigned long long *d_buffer) { g_integrate_debug = d_b
 static int integrate_zchunk(int z1) {
     static const int forced = std::getenv("KFH_INTEGRATE_ZCHUNK") ? std::atoi(std::getenv("KFH_INTEGRATE_ZCHUNK")) : 0;
     if (forced >= INTEGRATE_UNROLL && forced % INTEGRATE_UNROLL == 0) return forced;
-    return z1 <= 512 ? 16 : 64;      // measured at 512^3: 16 -> 35 us per integration, 32 -> 40 us, 64 -> 54 us
+    // measured per integration at 512^3: 16 -> 35 us, 32 -> 40 us, 64 -> 54 us; at 1024^3: 16 -> 126 us, 32 -> 104 us, 64 -> 107 us
+    return z1 <= 512 ? 16 : z1 <= 1024 ? 32 : 64;
 }
 
 size_t integrate_box_list_bytes(const int res[3], int z1) {

@@ -144,3 +144,30 @@ def test_properties_at_full_size(torch_cuda, cfg, stream):
     af = np.abs(f)
     assert np.median(af) < 0.01 and np.percentile(af, 95) < 0.1, (np.median(af), np.percentile(af, [90, 95, 99]))
     kf.close()
+
+
+def test_volume_beyond_4_gib_matches_the_oracle(torch_cuda, stream):
+    """1024^3 voxels are 4.3 GB: voxel offsets no longer fit 32 bits, so the raycast and the integration run
+    their 64-bit addressing variants.  Same comparison as at 512^3, on fewer frames."""
+    depth, gt, ts = stream
+    cfg = KFusionConfig(input_size=(640, 480), intrinsics=TUM_FR1_DEPTH_INTRINSICS, compute_size_ratio=1,
+                        volume_resolution=(1024, 1024, 1024))
+    kf_ref.set_threads(16)
+    ref = kf_ref.KFusionRef(oracle_config(cfg))
+    kf = KFusion(cfg)
+    for i in range(4):
+        ref.process_frame(depth[i])
+        kf.process_frame(depth[i])
+    assert np.array_equal(kf.pose, ref.pose)
+    got = kf.download(native.BUF_VOLUME)
+    assert np.array_equal(got[:512], ref.volume()[:512]) and np.array_equal(got[512:], ref.volume()[512:])
+    del got
+    assert np.array_equal(kf.download(native.BUF_MODEL_VERTEX)[..., :3], ref.model_vertex())
+    for i in range(4, 7):
+        flags = ref.process_frame(depth[i])
+        kf.process_frame(depth[i])
+        st = kf.status(i)
+        assert st["tracked"] and bool(flags & 1)
+        assert np.linalg.norm(st["pose"][:3, 3] - ref.pose[:3, 3]) < 1e-5
+    ref.close()
+    kf.close()
