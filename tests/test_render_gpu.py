@@ -149,3 +149,25 @@ def test_context_renders_match_oracle(torch_cuda):
     with pytest.raises(native.KfhError):
         kf.render(native.RENDER_TRACK)
     kf.close()
+
+
+def test_render_argument_errors(torch_cuda):
+    cfg = KFusionConfig(compute_size_ratio=8, volume_resolution=(32, 32, 32))
+    kf = KFusion(cfg)
+    with pytest.raises(native.KfhError) as e:
+        kf.render(7)
+    assert e.value.code == 1 and "unknown image" in str(e.value)
+    L = native.lib()
+    small = np.zeros(16, np.uint8)
+    rc = L.kfh_render(kf._ctx, native.RENDER_DEPTH, None, small.ctypes.data_as(C.c_void_p), C.c_size_t(small.nbytes))
+    assert rc == 1 and b"bytes" in L.kfh_last_error()
+    assert L.kfh_render(kf._ctx, native.RENDER_DEPTH, None, None, C.c_size_t(0)) == 1
+    kf.close()
+    # a z-slab context holds part of the volume only: no volume picture from it
+    slab = KFusionConfig(compute_size_ratio=8, volume_resolution=(32, 32, 32), slab=(8, 24))
+    ks = KFusion(slab)
+    with pytest.raises(native.KfhError) as e:
+        ks.render(native.RENDER_VOLUME)
+    assert e.value.code == 3
+    assert ks.render(native.RENDER_DEPTH).shape == (60, 80, 4)          # the other pictures do not need the volume
+    ks.close()
