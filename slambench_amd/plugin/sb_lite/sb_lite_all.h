@@ -4,7 +4,7 @@
 //
 // It is NOT binary compatible with a real `slambench` executable: the harness passes C++ objects
 // (vtables, std::string, std::map, Eigen matrices) across the plugin boundary, so a drop-in
-// libkfusion-hip-library.so must be compiled against the real headers.  Names,
+// libkfusion-hip-library.so must be compiled against the real headers (plugin/Makefile: SLAMBENCH_INCLUDE=...).  Names,
 // members and behaviour follow the reference headers cited at each class
 // (paths relative to framework/shared/include of the reference).
 #ifndef SB_LITE_ALL_H_
