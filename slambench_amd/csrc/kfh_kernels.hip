@@ -85,6 +85,11 @@ __global__ __launch_bounds__(256) void k_preprocess(float *__restrict__ raw, flo
     float result = 0.f;
     if (filtered && center != 0) {
         float sum = 0.0f, t = 0.0f;
+        // The reference evaluates expf(-mod / (2 * e_d^2)) in every tap.  Here: one reciprocal per pixel, folded
+        // with log2(e), and the hardware's 2^x (1 ulp).  The argument moves by about two units in the last place,
+        // so a weight differs by |argument| * 1e-7 relative: far inside the 1e-5 that the device's expf already
+        // differs from the host's by, and the centre tap (weight 1) bounds the sum from below.
+        const float inv_e = (1.0f / bc.e_d_squared_2) * 1.44269504088896341f;
 #pragma unroll
         for (int i = -PRE_R; i <= PRE_R; ++i) {
 #pragma unroll
@@ -92,7 +97,7 @@ __global__ __launch_bounds__(256) void k_preprocess(float *__restrict__ raw, flo
                 const float cur = tile[ty + PRE_R + j][tx + PRE_R + i];
                 if (cur > 0) {
                     const float mod = (cur - center) * (cur - center);
-                    const float factor = bc.g[i + PRE_R] * bc.g[j + PRE_R] * expf(-mod / bc.e_d_squared_2);
+                    const float factor = bc.g[i + PRE_R] * bc.g[j + PRE_R] * __builtin_amdgcn_exp2f(-mod * inv_e);
                     t += factor * cur;
                     sum += factor;
                 }
