@@ -2085,7 +2085,7 @@ __global__ __launch_bounds__(256, 5) void k_raycast_march(float4 *__restrict__ v
                                                        const Mat4 *__restrict__ view_p, float near_plane,
                                                        float far_plane, float step, float largestep,
                                                        RayTask *__restrict__ tasks, unsigned *task_count,
-                                                       int max_rounds, unsigned long long *dbg) {
+                                                       int max_rounds, int few, unsigned long long *dbg) {
     // 16x16 pixel block, each wavefront an 8x8 tile
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // diagnostics (dbg != null): per wavefront {start, end} of the 100 MHz counter, batches, rays handed over
@@ -2120,7 +2120,7 @@ __global__ __launch_bounds__(256, 5) void k_raycast_march(float4 *__restrict__ v
     if (dbg) dbg_loop_t0 = __builtin_amdgcn_s_memrealtime();
     while (true) {
         const unsigned long long alive = __ballot(marching);
-        if (alive == 0 || __popcll(alive) <= RAY_FEW || rounds == max_rounds) break;
+        if (alive == 0 || (int)__popcll(alive) <= few || rounds == max_rounds) break;
         ++rounds;
         bool dbg_round_heavy = false;
         unsigned long long dbg_round_t0 = 0;
@@ -2369,10 +2369,11 @@ static hipError_t launch_raycast_t(float4 *vertex, float4 *normal, float *ray_t,
     const dim3 grid((w + 15) / 16, (h + 15) / 16);
     // tuning knobs for experiments (defaults: RAY_MAX_ROUNDS, 32 lanes per unfinished ray)
     static const int max_rounds = std::getenv("KFH_RAY_ROUNDS") ? std::atoi(std::getenv("KFH_RAY_ROUNDS")) : RAY_MAX_ROUNDS;
+    static const int few = std::getenv("KFH_RAY_FEW") ? std::atoi(std::getenv("KFH_RAY_FEW")) : RAY_FEW;
     static const int tail_lanes = std::getenv("KFH_RAY_TAIL_LANES") ? std::atoi(std::getenv("KFH_RAY_TAIL_LANES")) : 32;
     hipLaunchKernelGGL((k_raycast_march<POW2, OFF32>), grid, dim3(256), 0, s, vertex, normal, ray_t, ref_tn, w, h, v, zc0, zc1,
                        view, near_plane, far_plane, step, largestep, static_cast<RayTask *>(tasks), task_count,
-                       max_rounds, g_raycast_debug);
+                       max_rounds, few, g_raycast_debug);
     const RayTask *ct = static_cast<const RayTask *>(tasks);
     if (tail_lanes == 64)
         hipLaunchKernelGGL((k_raycast_tail<POW2, OFF32, 64>), dim3(RAY_TAIL_BLOCKS * 2), dim3(256), 0, s, vertex, normal, ray_t,
