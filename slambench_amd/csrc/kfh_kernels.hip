@@ -1136,19 +1136,25 @@ __global__ __launch_bounds__(64 * (1 + PW)) void k_icp_iteration(const float *__
                 for (int i = 0; i < 6; ++i) td.J[i] = J[i];
                 a.track_out[x + yy[k] * a.track_stride] = td;
             }
-            // rows and columns past the image edge repeat the edge pixel: they add zeros
-            const float e = live[k] ? error : 0.f;
+            // Rows and columns past the image edge repeat the edge pixel: they add zeros.  The products go into
+            // the sums by fused multiply-add: one rounding instead of the reference's two, a difference of half a
+            // unit in the last place of a term, far below what the different order of summation already makes.
+            const bool counted = live[k] && valid;
+            const float e = counted ? error : 0.f;
             float Jl[6];
 #pragma unroll
-            for (int i = 0; i < 6; ++i) Jl[i] = live[k] ? J[i] : 0.f;
-            acc[0] += e * e;
+            for (int i = 0; i < 6; ++i) Jl[i] = counted ? J[i] : 0.f;
+            acc[0] = fmaf(e, e, acc[0]);
 #pragma unroll
-            for (int i = 0; i < 6; ++i) acc[1 + i] += e * Jl[i];
+            for (int i = 0; i < 6; ++i) acc[1 + i] = fmaf(e, Jl[i], acc[1 + i]);
             int q = 7;
 #pragma unroll
             for (int i = 0; i < 6; ++i)
 #pragma unroll
-                for (int j = i; j < 6; ++j) acc[q++] += Jl[i] * Jl[j];
+                for (int j = i; j < 6; ++j) {
+                    acc[q] = fmaf(Jl[i], Jl[j], acc[q]);
+                    ++q;
+                }
             acc[28] += (live[k] && valid) ? 1.f : 0.f;
             acc[29] += (live[k] && result == -4) ? 1.f : 0.f;
             acc[30] += (live[k] && result == -5) ? 1.f : 0.f;
