@@ -836,6 +836,7 @@ int kfh_debug_raycast_stats(kfh_context *c, unsigned long long *h_out) {
 int kfh_debug_icp_stamps(kfh_context *c, unsigned long long *h_out) {
     KFH_REQUIRE(c != nullptr && h_out != nullptr, "NULL argument");
     if (!c->d_stamps) return fail(KFH_ERR_STATE, "context was created without KFH_ICP_STAMPS");
+    if (!icp_stamps_compiled()) return fail(KFH_ERR_STATE, "this library was built without time stamps (make -C slambench_amd/csrc STAMPS=1)");
     KFH_HIP(hipStreamSynchronize(c->stream));
     KFH_HIP(hipMemcpy(h_out, c->d_stamps,
                       (size_t)KFH_STAMP_LAUNCHES * KFH_STAMP_BLOCKS * KFH_STAMP_SLOTS * sizeof(unsigned long long),

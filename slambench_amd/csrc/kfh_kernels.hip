@@ -802,9 +802,15 @@ __device__ inline void icp_store_state(IcpState *out, const IcpShared<PW> &sh, i
 }
 
 // Diagnostic time stamps (100 MHz real-time counter) of lane 0 of wavefront w, when a stamp buffer is given.
+// Only in builds made with `make STAMPS=1`: the tests and branches cost the iteration kernel about 1 % even
+// when no buffer is given.
+#ifndef KFH_STAMPS_COMPILED
+#define KFH_STAMPS_COMPILED 0
+#endif
+bool icp_stamps_compiled() { return KFH_STAMPS_COMPILED != 0; }
 #define KFH_STAMP(slot, w)                                                                                   \
     do {                                                                                                     \
-        if (a.stamps != nullptr && threadIdx.x == 64 * (w) && blockIdx.x < KFH_STAMP_BLOCKS &&               \
+        if (KFH_STAMPS_COMPILED && a.stamps != nullptr && threadIdx.x == 64 * (w) && blockIdx.x < KFH_STAMP_BLOCKS &&               \
             a.seq < KFH_STAMP_LAUNCHES) {                                                                    \
             __builtin_amdgcn_sched_barrier(0);                                                               \
             a.stamps[((size_t)a.seq * KFH_STAMP_BLOCKS + blockIdx.x) * KFH_STAMP_SLOTS + (slot)] =           \
@@ -899,7 +905,7 @@ __global__ __launch_bounds__(64 * (1 + PW)) void k_icp_iteration(const float *__
     a.ih = pre_ih;
     __shared__ IcpShared<PW> sh;
     KFH_STAMP(0, 0);
-    if (a.stamps != nullptr && threadIdx.x == 0 && blockIdx.x < KFH_STAMP_BLOCKS && a.seq < KFH_STAMP_LAUNCHES)
+    if (KFH_STAMPS_COMPILED && a.stamps != nullptr && threadIdx.x == 0 && blockIdx.x < KFH_STAMP_BLOCKS && a.seq < KFH_STAMP_LAUNCHES)
         a.stamps[((size_t)a.seq * KFH_STAMP_BLOCKS + blockIdx.x) * KFH_STAMP_SLOTS + 12] = __builtin_amdgcn_s_memtime();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int pw = wave - 1;                          // pixel wavefront index; wavefront 0 has no pixels
@@ -1182,7 +1188,7 @@ __global__ __launch_bounds__(64 * (1 + PW)) void k_icp_iteration(const float *__
         if (blockIdx.x == 0) icp_store_state(out, sh, gridDim.x, a.level, a.last_iter);
     }
     KFH_STAMP(6, 0);
-    if (a.stamps != nullptr && threadIdx.x == 0 && blockIdx.x < KFH_STAMP_BLOCKS && a.seq < KFH_STAMP_LAUNCHES)
+    if (KFH_STAMPS_COMPILED && a.stamps != nullptr && threadIdx.x == 0 && blockIdx.x < KFH_STAMP_BLOCKS && a.seq < KFH_STAMP_LAUNCHES)
         a.stamps[((size_t)a.seq * KFH_STAMP_BLOCKS + blockIdx.x) * KFH_STAMP_SLOTS + 13] = __builtin_amdgcn_s_memtime();
 }
 

@@ -6,6 +6,9 @@ wavefront done (rows folded, 6x6 solved, pose updated), 7 pixel wavefront 1 done
 model map gathered, 5 residuals accumulated, 6 partial row stored; 8 / 9 / 10: wavefront 4 prepared, residuals
 done, reduced.  Printed per launch: median and
 maximum over the blocks, in microseconds relative to the first block's entry.
+
+Needs a library built with the stamps: make -C slambench_amd/csrc clean && make -C slambench_amd/csrc STAMPS=1
+(and a plain rebuild afterwards).
 """
 import ctypes as C, os, sys
 os.environ["KFH_ICP_STAMPS"] = "1"
