@@ -784,6 +784,7 @@ int kfh_debug_solver_us(const float *h_sums32, float *us_per_update) {
 // h_out holds n_values = boxes * 4 wavefronts * 4 values + 1; the last one receives the number of boxes kept.
 int kfh_debug_integrate_stats(kfh_context *c, unsigned long long *h_out, size_t n_values) {
     KFH_REQUIRE(c != nullptr && h_out != nullptr, "NULL argument");
+    if (!icp_stamps_compiled()) return fail(KFH_ERR_STATE, "this library was built without diagnostics (make -C slambench_amd/csrc clean && make -C slambench_amd/csrc STAMPS=1)");
     unsigned long long *d = nullptr;
     KFH_HIP(hipMalloc(reinterpret_cast<void **>(&d), n_values * sizeof(unsigned long long)));
     KFH_HIP(hipMemset(d, 0, n_values * sizeof(unsigned long long)));
@@ -810,6 +811,7 @@ int kfh_debug_integrate_stats(kfh_context *c, unsigned long long *h_out, size_t 
 // second pass received.
 int kfh_debug_raycast_stats(kfh_context *c, unsigned long long *h_out) {
     KFH_REQUIRE(c != nullptr && h_out != nullptr, "NULL argument");
+    if (!icp_stamps_compiled()) return fail(KFH_ERR_STATE, "this library was built without diagnostics (make -C slambench_amd/csrc clean && make -C slambench_amd/csrc STAMPS=1)");
     const size_t n = (size_t)((c->w + 15) / 16) * ((c->h + 15) / 16) * 16;
     unsigned long long *d = nullptr;
     KFH_HIP(hipMalloc(reinterpret_cast<void **>(&d), n * sizeof(unsigned long long)));
@@ -836,7 +838,7 @@ int kfh_debug_raycast_stats(kfh_context *c, unsigned long long *h_out) {
 int kfh_debug_icp_stamps(kfh_context *c, unsigned long long *h_out) {
     KFH_REQUIRE(c != nullptr && h_out != nullptr, "NULL argument");
     if (!c->d_stamps) return fail(KFH_ERR_STATE, "context was created without KFH_ICP_STAMPS");
-    if (!icp_stamps_compiled()) return fail(KFH_ERR_STATE, "this library was built without time stamps (make -C slambench_amd/csrc STAMPS=1)");
+    if (!icp_stamps_compiled()) return fail(KFH_ERR_STATE, "this library was built without diagnostics (make -C slambench_amd/csrc clean && make -C slambench_amd/csrc STAMPS=1)");
     KFH_HIP(hipStreamSynchronize(c->stream));
     KFH_HIP(hipMemcpy(h_out, c->d_stamps,
                       (size_t)KFH_STAMP_LAUNCHES * KFH_STAMP_BLOCKS * KFH_STAMP_SLOTS * sizeof(unsigned long long),

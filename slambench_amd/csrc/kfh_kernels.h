@@ -122,7 +122,7 @@ hipError_t launch_half_sample(float *out, const float *in, int iw, int ih, float
 hipError_t launch_vertex_normal(float4 *vertex, float4 *normal, const float *depth, int w, int h, float fx,
                                 float fy, float cx, float cy, hipStream_t s);
 hipError_t launch_icp_iteration(const IcpIterArgs &a, hipStream_t s);
-bool icp_stamps_compiled();   // the library was built with the diagnostic time stamps (make STAMPS=1)
+bool icp_stamps_compiled();   // the library was built with its diagnostics: ICP time stamps, per-wavefront raycast / integrate records (make STAMPS=1)
 hipError_t launch_icp_finish(const FinishArgs &a, hipStream_t s);
 // tracking skipped (tracking-rate) or no iterations configured: record "not tracked" and derive matrices
 hipError_t launch_track_skip(const FinishArgs &a, hipStream_t s);

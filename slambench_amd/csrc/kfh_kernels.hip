@@ -1645,6 +1645,7 @@ __global__ __launch_bounds__(256) void k_integrate_plan(IntegrateArgs a) {
 
 // Second launch: a workgroup takes boxes from the list; one thread per (x, y) column of the box.
 __global__ __launch_bounds__(256) void k_integrate(IntegrateArgs a) {
+    if (!KFH_STAMPS_COMPILED) a.dbg = nullptr;      // per-wavefront statistics only in diagnostic builds
     const unsigned nbox = *a.box_count;
     if (nbox == 0) return;
     // diagnostics (dbg != null): per box and wavefront {start, end} of the 100 MHz counter, candidates, written
@@ -2101,6 +2102,7 @@ __global__ __launch_bounds__(256, 5) void k_raycast_march(float4 *__restrict__ v
     // 16x16 pixel block, each wavefront an 8x8 tile
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // diagnostics (dbg != null): per wavefront {start, end} of the 100 MHz counter, batches, rays handed over
+    if (!KFH_STAMPS_COMPILED) dbg = nullptr;        // per-wavefront statistics only in diagnostic builds
     unsigned long long dbg_t0 = 0;
     if (dbg) dbg_t0 = __builtin_amdgcn_s_memrealtime();
     const int x = blockIdx.x * 16 + (wave & 1) * 8 + (lane & 7);

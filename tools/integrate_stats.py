@@ -1,4 +1,7 @@
-"""Diagnostic: per-wavefront duration / work statistics of one integrate launch on the bench stream."""
+"""Diagnostic: per-wavefront duration / work statistics of one integrate launch on the bench stream.
+
+Needs a diagnostic build: make -C slambench_amd/csrc clean && make -C slambench_amd/csrc STAMPS=1 (rebuild plainly afterwards).
+"""
 import ctypes as C, os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
