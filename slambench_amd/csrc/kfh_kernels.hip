@@ -1098,8 +1098,6 @@ __global__ __launch_bounds__(64 * (1 + PW)) void k_icp_iteration(const float *__
         }
         KFH_STAMP(4, 1);
         float acc[32];
-#pragma unroll
-        for (int i = 0; i < 32; ++i) acc[i] = 0.0f;
         int code[PPT];
 #pragma unroll
         for (int k = 0; k < PPT; ++k) {
@@ -1150,21 +1148,26 @@ __global__ __launch_bounds__(64 * (1 + PW)) void k_icp_iteration(const float *__
             float Jl[6];
 #pragma unroll
             for (int i = 0; i < 6; ++i) Jl[i] = counted ? J[i] : 0.f;
-            acc[0] = fmaf(e, e, acc[0]);
+            // the first pixel starts the sums (a product is the fused multiply-add onto zero), the others add
+            const bool first = k == 0;
+            acc[0] = first ? e * e : fmaf(e, e, acc[0]);
 #pragma unroll
-            for (int i = 0; i < 6; ++i) acc[1 + i] = fmaf(e, Jl[i], acc[1 + i]);
+            for (int i = 0; i < 6; ++i) acc[1 + i] = first ? e * Jl[i] : fmaf(e, Jl[i], acc[1 + i]);
             int q = 7;
 #pragma unroll
             for (int i = 0; i < 6; ++i)
 #pragma unroll
                 for (int j = i; j < 6; ++j) {
-                    acc[q] = fmaf(Jl[i], Jl[j], acc[q]);
+                    acc[q] = first ? Jl[i] * Jl[j] : fmaf(Jl[i], Jl[j], acc[q]);
                     ++q;
                 }
-            acc[28] += (live[k] && valid) ? 1.f : 0.f;
-            acc[29] += (live[k] && result == -4) ? 1.f : 0.f;
-            acc[30] += (live[k] && result == -5) ? 1.f : 0.f;
-            acc[31] += (live[k] && result < 1 && result > -4) ? 1.f : 0.f;
+            const float c28 = (live[k] && valid) ? 1.f : 0.f, c29 = (live[k] && result == -4) ? 1.f : 0.f;
+            const float c30 = (live[k] && result == -5) ? 1.f : 0.f;
+            const float c31 = (live[k] && result < 1 && result > -4) ? 1.f : 0.f;
+            acc[28] = first ? c28 : acc[28] + c28;
+            acc[29] = first ? c29 : acc[29] + c29;
+            acc[30] = first ? c30 : acc[30] + c30;
+            acc[31] = first ? c31 : acc[31] + c31;
         }
         KFH_STAMP(5, 1);
         KFH_STAMP(9, 4);
