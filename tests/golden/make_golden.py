@@ -35,8 +35,9 @@ def build():
     vtx = kf_ref.depth2vertex(filt, kf_ref.inverse_camera_matrix(k))
     out["depth2vertex"] = vtx
     out["vertex2normal"] = kf_ref.vertex2normal(vtx)
-    # pipeline at 64x48 input, compute ratio 1, 32^3 volume
-    cfg = KFusionConfig(input_size=(64, 48), intrinsics=tuple(k), volume_resolution=(32, 32, 32))
+    # pipeline at 64x48 input, compute ratio 1, 64^3 volume; mu = 0.3 so that the truncation band spans more than
+    # two of the 12.5 cm voxels (with the default 0.1 nothing of the surface survives and tracking never starts)
+    cfg = KFusionConfig(input_size=(64, 48), intrinsics=tuple(k), volume_resolution=(64, 64, 64), mu=0.3)
     ref = kf_ref.KFusionRef(cfg.to_c(kf_ref.Config))
     poses, flags = [], []
     for i in range(n):
@@ -56,6 +57,12 @@ def build():
             sums = kf_ref.reduce(td, 64, 48)
             out["reduce_f7"] = sums
             out["solve_f7"] = kf_ref.solve(sums[1:28])
+            # the three GUI pictures: raw depth of this frame, the tracking codes of its last ICP iteration, the shaded volume
+            out["render_depth_f7"] = kf_ref.render_depth(ref.float_depth(), 0.4, 4.0)
+            out["render_track_f7"] = kf_ref.render_track(ref.tracking_result())    # codes of the frame's last iteration
+            rview = kf_ref.mat_mul(ref.pose, kf_ref.inverse_camera_matrix(K))
+            out["render_volume_f7"] = kf_ref.render_volume(ref.volume(), cfg.volume_size, 64, 48, rview, 0.4, 8.0,
+                                                           None, float(np.float32(0.75) * np.float32(cfg.mu)))
     out["pipeline_poses"] = np.stack(poses)
     out["pipeline_flags"] = np.asarray(flags, np.int32)
     out["se3_exp"] = kf_ref.se3_exp(np.array([0.01, -0.02, 0.03, 0.2, -0.1, 0.05]))

@@ -40,10 +40,18 @@ def test_synthetic_stream_is_deterministic(gold, fresh):
 
 
 @pytest.mark.parametrize("key", ["mm2meters", "mm2meters_half", "half_sample", "depth2vertex", "track_result_f7",
-                                 "pipeline_flags"])
+                                 "pipeline_flags", "render_depth_f7", "render_track_f7"])
 def test_integer_and_exact_float_kernels(gold, fresh, key):
     """Index work and expressions without transcendental functions reproduce bit for bit."""
     assert np.array_equal(gold[key], fresh[key]), key
+
+
+def test_shaded_volume_picture(gold, fresh):
+    """Bytes of a float shading (square roots and divisions only, both correctly rounded): equal, except that a
+    value within rounding of a byte boundary may fall on either side on another libm / compiler."""
+    a, b = gold["render_volume_f7"].astype(np.int32), fresh["render_volume_f7"].astype(np.int32)
+    assert (a[..., :3].max(axis=-1) > 0).mean() > 0.2                  # the picture shows something
+    assert np.abs(a - b).max() <= 1 and (a != b).mean() < 1e-3
 
 
 @pytest.mark.parametrize("key", ["bilateral", "vertex2normal", "volume_f7", "model_vertex_f7", "model_normal_f7",
