@@ -1,4 +1,4 @@
-"""Diagnostic: per-frame pose difference between the HIP pipeline and the oracle on a synthetic stream."""
+"""Diagnostic (test infrastructure: it uses the oracle): per-frame pose difference between the HIP pipeline and the oracle on a synthetic stream."""
 import argparse
 import os
 import sys
