@@ -137,3 +137,24 @@ def test_parameter_sweep_through_the_harness(torch_cuda, tmp_path):
     assert all(r.summary["frames"] == n and r.summary["mean_frame_s"] > 0 for r in res)
     assert res[1].summary["ate_rmse_m"] < 0.02                     # 128^3 tracks the synthetic room
     assert res[0].summary["last_position"] != res[1].summary["last_position"]
+
+
+def test_run_script_writes_a_complete_log(torch_cuda, tmp_path):
+    import os
+    import subprocess
+    import sys
+    from slambench_amd import slamfile
+    n = 8
+    intr = (481.2, 480.0, 319.5, 239.5)
+    depth, gt, ts = synth.make_sequence(n, seed=2, intrinsics=intr)
+    slam, log = str(tmp_path / "s.slam"), str(tmp_path / "run.log")
+    slamfile.write_depth_sequence(slam, depth, ts, intr, gt_poses=gt, with_rgb_and_grey=False)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "slambench_run.py"), slam, "-o", log, "--",
+                        "-c", "4", "-v", "128,128,128"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    props, cols, rows = harness.parse_log(open(log).read())
+    assert cols[:7] == ["Frame Number", "Timestamp"] + list(harness.ACCURACY_COLUMNS)
+    assert cols[7] == "Duration_Frame" and cols[-3:] == ["X", "Y", "Z"] and rows.shape == (n, len(cols))
+    assert props["volume-resolution"] == "128,128,128"
+    assert rows[-1, cols.index("ATE_RMSE")] < 0.02
