@@ -200,3 +200,45 @@ def test_degenerate_frames_match_oracle(torch_cuda):
     assert np.isfinite(kf.download(native.BUF_MODEL_VERTEX)).all()
     assert int(vol[..., 1].max()) <= 100 and int(np.abs(vol[..., 0].astype(np.int32)).max()) <= 32766
     kf.close()
+
+
+_HASH_SNIPPET = """
+import hashlib, sys
+import numpy as np
+sys.path.insert(0, %r)
+from slambench_amd import native, synth
+from slambench_amd.config import KFusionConfig
+from slambench_amd.kfusion import KFusion
+cfg = KFusionConfig(compute_size_ratio=2, volume_resolution=(128, 128, 128))
+depth, _, _ = synth.make_sequence(16, seed=6, noise=True)
+kf = KFusion(cfg)
+for i in range(16):
+    kf.process_frame(depth[i])           # host frames: the upload path is part of what is compared
+h = hashlib.sha256()
+for a in (kf.trajectory(), kf.download(native.BUF_VOLUME), kf.download(native.BUF_MODEL_VERTEX),
+          kf.download(native.BUF_MODEL_NORMAL), kf.render(native.RENDER_VOLUME)):
+    h.update(np.ascontiguousarray(a).tobytes())
+print("HASH", h.hexdigest(), int(kf.status(15)["tracked"]))
+"""
+
+
+def test_tuning_switches_do_not_change_results(torch_cuda):
+    """The environment switches select other launch shapes, skip optimisations or take another transfer path;
+    every one of them must produce the same bits as the default."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    variants = [{}, {"KFH_NO_BRICK_MARKS": "1"}, {"KFH_NO_DEPTH_CULL": "1"}, {"KFH_INTEGRATE_ZCHUNK": "64"},
+                {"KFH_INTEGRATE_ZCHUNK": "8", "KFH_RAY_ROUNDS": "3", "KFH_RAY_FEW": "32"},
+                {"KFH_RAY_TAIL_LANES": "16", "KFH_UPLOAD_COPY_ENGINE": "1"}, {"KFH_OVERLAP_PREPROCESS": "1"}]
+    hashes = []
+    for extra in variants:
+        env = dict(os.environ)
+        env.update(extra)
+        r = subprocess.run([sys.executable, "-c", _HASH_SNIPPET % root], capture_output=True, text=True, env=env, timeout=300)
+        assert r.returncode == 0, (extra, r.stderr[-2000:])
+        line = [l for l in r.stdout.splitlines() if l.startswith("HASH")][0].split()
+        assert line[2] == "1", extra                        # the last frame tracked
+        hashes.append(line[1])
+    assert len(set(hashes)) == 1, list(zip(variants, hashes))
