@@ -2,6 +2,9 @@
 #ifndef KFH_KERNELS_H_
 #define KFH_KERNELS_H_
 
+#include <cstdio>
+#include <cstdlib>
+
 #include "kfh_device.h"
 #include "../../include/kfusion_hip.h"
 
@@ -41,7 +44,7 @@ struct Ctrl {
 };
 
 // Tracking block: wavefront 0 finalises the previous iteration (row sum, 6x6 solve, pose update) while
-// PW pixel wavefronts (4 or 8) prepare and then evaluate the pixels of a 64 x (PW * PPT) tile, PPT rows per
+// PW pixel wavefronts (3 to 8) prepare and then evaluate the pixels of a 64 x (PW * PPT) tile, PPT rows per
 // thread.  A SIMD issues one vector instruction every 4 cycles for a lone wavefront but every 2 cycles with
 // two, so 8 pixel wavefronts (two per SIMD) evaluate twice the tile in the same time.
 constexpr int KFH_TRACK_TILE_W = 64;
@@ -59,7 +62,19 @@ inline int track_blocks(int w, int h, int pw, int ppt) {
 // thread whose grid still fits on `max_blocks` compute units at one block each (no unit gets a second tile);
 // ties go to the smaller block.
 inline void track_shape(int w, int h, int max_blocks, int *pw, int *ppt) {
-    static const int shapes[][2] = {{4, 1}, {8, 1}, {4, 2}, {8, 2}, {4, 3}, {8, 3}, {4, 5}, {8, 5}, {4, 8}, {8, 8}};
+    static const int shapes[][2] = {{3, 1}, {4, 1}, {5, 1}, {6, 1}, {8, 1}, {4, 2}, {8, 2}, {4, 3}, {7, 3}, {8, 3}, {4, 5}, {8, 5}, {4, 8}, {8, 8}};
+    // experiments: KFH_TRACK_SHAPE_<image width>=pw,ppt forces an (instantiated) shape for images of that width
+    {
+        char name[40];
+        std::snprintf(name, sizeof(name), "KFH_TRACK_SHAPE_%d", w);
+        const char *v = std::getenv(name);
+        int fp = 0, fq = 0;
+        if (v && std::sscanf(v, "%d,%d", &fp, &fq) == 2 && fp > 0 && fq > 0) {
+            *pw = fp;
+            *ppt = fq;
+            return;
+        }
+    }
     for (const auto &sh : shapes)
         if (track_blocks(w, h, sh[0], sh[1]) <= max_blocks) {
             *pw = sh[0];

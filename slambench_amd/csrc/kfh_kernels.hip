@@ -1204,23 +1204,22 @@ static float max_arg_with_sqrt_le(float t) {
     return c;
 }
 
-template <bool PACKED, int PW>
-static bool launch_icp_ppt(const IcpIterArgs &a, int nb, hipStream_t s) {
-    const dim3 g(nb), b(64 * (1 + PW));
-    switch (a.ppt) {
-        case 1: hipLaunchKernelGGL((k_icp_iteration<PACKED, PW, 1>), g, b, 0, s, a.partials_in, a.ctrl, a.in_depth,
-                                    a.stamps, a.pending_rows, a.seq, a.iw, a.ih, a); return true;
-        case 2: hipLaunchKernelGGL((k_icp_iteration<PACKED, PW, 2>), g, b, 0, s, a.partials_in, a.ctrl, a.in_depth,
-                                    a.stamps, a.pending_rows, a.seq, a.iw, a.ih, a); return true;
-        case 3: hipLaunchKernelGGL((k_icp_iteration<PACKED, PW, 3>), g, b, 0, s, a.partials_in, a.ctrl, a.in_depth,
-                                    a.stamps, a.pending_rows, a.seq, a.iw, a.ih, a); return true;
-        case 5: hipLaunchKernelGGL((k_icp_iteration<PACKED, PW, 5>), g, b, 0, s, a.partials_in, a.ctrl, a.in_depth,
-                                    a.stamps, a.pending_rows, a.seq, a.iw, a.ih, a); return true;
-        case 8: hipLaunchKernelGGL((k_icp_iteration<PACKED, PW, 8>), g, b, 0, s, a.partials_in, a.ctrl, a.in_depth,
-                                    a.stamps, a.pending_rows, a.seq, a.iw, a.ih, a); return true;
-        default: return false;
+// The instantiated block shapes: every (pixel wavefronts, rows per thread) pair track_shape can return.
+#define KFH_ICP_SHAPE(PW_, PPT_)                                                                              \
+    if (a.pw == PW_ && a.ppt == PPT_) {                                                                      \
+        hipLaunchKernelGGL((k_icp_iteration<PACKED, PW_, PPT_>), dim3(nb), dim3(64 * (1 + PW_)), 0, s,      \
+                           a.partials_in, a.ctrl, a.in_depth, a.stamps, a.pending_rows, a.seq, a.iw, a.ih, a); \
+        return true;                                                                                         \
     }
+template <bool PACKED>
+static bool launch_icp_shape(const IcpIterArgs &a, int nb, hipStream_t s) {
+    KFH_ICP_SHAPE(3, 1) KFH_ICP_SHAPE(4, 1) KFH_ICP_SHAPE(5, 1) KFH_ICP_SHAPE(6, 1) KFH_ICP_SHAPE(8, 1)
+    KFH_ICP_SHAPE(4, 2) KFH_ICP_SHAPE(8, 2)
+    KFH_ICP_SHAPE(4, 3) KFH_ICP_SHAPE(7, 3) KFH_ICP_SHAPE(8, 3)
+    KFH_ICP_SHAPE(4, 5) KFH_ICP_SHAPE(8, 5) KFH_ICP_SHAPE(4, 8) KFH_ICP_SHAPE(8, 8)
+    return false;
 }
+#undef KFH_ICP_SHAPE
 
 hipError_t launch_icp_iteration(const IcpIterArgs &a_in, hipStream_t s) {
     IcpIterArgs a = a_in;
@@ -1235,10 +1234,7 @@ hipError_t launch_icp_iteration(const IcpIterArgs &a_in, hipStream_t s) {
     }
     const int nb = track_blocks(a.iw, a.ih, a.pw, a.ppt);
     bool ok = false;
-    if (packed && a.pw == 4) ok = launch_icp_ppt<true, 4>(a, nb, s);
-    else if (packed && a.pw == 8) ok = launch_icp_ppt<true, 8>(a, nb, s);
-    else if (!packed && a.pw == 4) ok = launch_icp_ppt<false, 4>(a, nb, s);
-    else if (!packed && a.pw == 8) ok = launch_icp_ppt<false, 8>(a, nb, s);
+    ok = packed ? launch_icp_shape<true>(a, nb, s) : launch_icp_shape<false>(a, nb, s);
     if (!ok) return hipErrorInvalidValue;
     return hipGetLastError();
 }
