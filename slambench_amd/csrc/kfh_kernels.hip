@@ -314,9 +314,11 @@ __device__ inline float fold_row_slots_wave0(const float *lds) {
     constexpr int HALF = PartialRows<NT>::SLOTS / 2;
     static_assert(PartialRows<NT>::SLOTS % 2 == 0, "slot count must be even");
     const int lane = threadIdx.x & 63, col = lane & 31, half = lane >> 5;
-    float s = 0.f;
+    // four interleaved partial sums (slots k, k + 4, ...), combined pairwise: a quarter of the dependent additions
+    float s4[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int k = 0; k < HALF; ++k) s += lds[(half * HALF + k) * 32 + col];
+    for (int k = 0; k < HALF; ++k) s4[k & 3] += lds[(half * HALF + k) * 32 + col];
+    const float s = (s4[0] + s4[1]) + (s4[2] + s4[3]);
     return s + __shfl_xor(s, 32, 64);
 }
 
