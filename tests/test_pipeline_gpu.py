@@ -113,7 +113,7 @@ def test_brick_marks_are_conservative(torch_cuda):
 
 
 def test_tracking_rate_and_filtered_integration(torch_cuda):
-    cfg = KFusionConfig(compute_size_ratio=4, volume_resolution=(64, 64, 64), tracking_rate=2, integration_rate=3,
+    cfg = KFusionConfig(compute_size_ratio=4, volume_resolution=(128, 128, 128), tracking_rate=2, integration_rate=3,
                         integrate_filtered=True, pyramid=(4, 3, 2))
     depth, gt, ts = synth.make_sequence(14, seed=2)
     ref, kf, flags_ref, poses_ref = _run_both(cfg, depth)
@@ -122,15 +122,18 @@ def test_tracking_rate_and_filtered_integration(torch_cuda):
         want = flags_ref[f]
         assert (st["tracked"], st["integrated"], st["raycasted"]) == (bool(want & 1), bool(want & 2), bool(want & 4)), f
         assert np.linalg.norm(st["pose"][:3, 3] - poses_ref[f][:3, 3]) < 1e-3
+    # with tracking-rate 2 only even frames can track, and some of them did
+    assert any(bool(f & 1) for f in flags_ref) and not any(bool(flags_ref[f] & 1) for f in range(1, 14, 2))
     kf.close()
 
 
 def test_reset_and_set_pose(torch_cuda):
-    cfg = KFusionConfig(compute_size_ratio=4, volume_resolution=(64, 64, 64))
+    cfg = KFusionConfig(compute_size_ratio=4, volume_resolution=(128, 128, 128))
     depth, gt, ts = synth.make_sequence(6, seed=1)
     kf = KFusion(cfg)
     for i in range(6):
         kf.process_frame(depth[i])
+    assert kf.status(5)["tracked"]                           # the pose has moved: the reset below is observable
     p1 = kf.pose.copy()
     v1 = kf.download(native.BUF_VOLUME)
     kf.reset()
@@ -140,6 +143,7 @@ def test_reset_and_set_pose(torch_cuda):
     assert np.array_equal(kf.pose, p0)
     vol0 = kf.download(native.BUF_VOLUME)
     assert (vol0[..., 0] == 32766).all() and (vol0[..., 1] == 0).all()
+    assert not np.array_equal(p1, p0)
     for i in range(6):
         kf.process_frame(depth[i])
     assert np.array_equal(kf.pose, p1)                       # deterministic run to run

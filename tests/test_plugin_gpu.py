@@ -15,10 +15,10 @@ def test_mini_harness_matches_direct_pipeline(torch_cuda, tmp_path):
     depth, gt, ts = synth.make_sequence(n, seed=1, intrinsics=intr)
     path = str(tmp_path / "stream.kfd")
     harness.write_kfd(path, depth, ts, intr, 0.001)
-    r = harness.run_mini_harness(path, ["--compute-size-ratio", "4", "--volume-resolution", "64,64,64", "-m", "0.1"])
+    r = harness.run_mini_harness(path, ["--compute-size-ratio", "4", "--volume-resolution", "128,128,128", "-m", "0.1"])
     assert r.returncode == 0, r.stderr
     props, cols, rows = harness.parse_log(r.stdout)
-    assert props["compute-size-ratio"] == "4" and props["volume-resolution"] == "64,64,64"
+    assert props["compute-size-ratio"] == "4" and props["volume-resolution"] == "128,128,128"
     assert props["integration-rate"] == "2" and props["pyramid-level1"] == "10"
     assert cols[:3] == ["Frame Number", "Timestamp", "Duration_Frame"]
     assert cols[3:8] == ["Duration_Preprocessing", "Duration_Tracking", "Duration_Integration",
@@ -29,10 +29,11 @@ def test_mini_harness_matches_direct_pipeline(torch_cuda, tmp_path):
     w, h = 640, 480
     intr_rt = tuple(np.float32(v / s) * np.float32(s) for v, s in zip(intr, (w, h, w, h)))
     kf = KFusion(KFusionConfig(intrinsics=tuple(float(v) for v in intr_rt), compute_size_ratio=4,
-                               volume_resolution=(64, 64, 64)))
+                               volume_resolution=(128, 128, 128)))
     for i in range(n):
         kf.process_frame(depth[i])
     traj = kf.trajectory()
+    assert kf.status(n - 1)["tracked"] and np.abs(traj[-1, :3, 3] - 4.0).max() > 1e-3    # the camera moved
     np.testing.assert_allclose(rows[:, 8:11], traj[:, :3, 3], rtol=0, atol=1e-6)
     assert np.allclose(rows[:4, 8:11], 4.0)            # pose frozen until the model exists
     kf.close()
@@ -65,7 +66,7 @@ def test_slam_file_input_matches_kfd_input(torch_cuda, tmp_path):
     kfd, slam = str(tmp_path / "s.kfd"), str(tmp_path / "s.slam")
     harness.write_kfd(kfd, depth, ts, intr, 0.001)
     slamfile.write_depth_sequence(slam, depth, ts, intr, gt_poses=gt, disparity_scale=0.001)
-    args = ["-c", "4", "-v", "64,64,64"]
+    args = ["-c", "4", "-v", "128,128,128"]
     a = harness.run_mini_harness(kfd, args)
     b = harness.run_mini_harness(slam, args)
     assert a.returncode == 0 and b.returncode == 0, (a.stderr, b.stderr)
