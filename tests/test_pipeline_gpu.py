@@ -246,3 +246,24 @@ def test_tuning_switches_do_not_change_results(torch_cuda):
         assert line[2] == "1", extra                        # the last frame tracked
         hashes.append(line[1])
     assert len(set(hashes)) == 1, list(zip(variants, hashes))
+
+
+@pytest.mark.parametrize("csr,res,size,vol_size", [
+    (8, (96, 96, 96), (640, 480), (8.0, 8.0, 8.0)),             # 80 x 60 compute image: partial tiles everywhere
+    (1, (100, 120, 90), (320, 240), (8.0, 8.0, 8.0)),           # no power of two in the volume, anisotropic voxels
+    (2, (160, 128, 144), (640, 480), (6.0, 7.0, 8.0)),          # non-cubic metric size
+])
+def test_odd_shapes_match_oracle(torch_cuda, csr, res, size, vol_size):
+    from slambench_amd.config import ICL_NUIM_INTRINSICS
+    intr = tuple(v * size[0] / 640 for v in ICL_NUIM_INTRINSICS)
+    centre = tuple(0.5 * v for v in vol_size)
+    cfg = KFusionConfig(input_size=size, intrinsics=intr, compute_size_ratio=csr, volume_resolution=res,
+                        volume_size=vol_size, volume_direction=centre)
+    depth, gt, ts = synth.make_sequence(10, seed=7, intrinsics=intr, size=size, noise=True)
+    ref, kf, flags_ref, poses_ref = _run_both(cfg, depth)
+    for f in range(10):
+        st = kf.status(f)
+        want = flags_ref[f]
+        assert (st["tracked"], st["integrated"], st["raycasted"]) == (bool(want & 1), bool(want & 2), bool(want & 4)), f
+        assert np.linalg.norm(st["pose"][:3, 3] - poses_ref[f][:3, 3]) < 1e-4, f
+    kf.close()
