@@ -60,6 +60,18 @@ def ping_pong(n_unique, count):
     return [period[i % len(period)] for i in range(count)]
 
 
+def cpu_model():
+    """First "model name" of /proc/cpuinfo, as the reference's log header prints it (ResultWriter.cpp:49-75)."""
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.lower().startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(cfg, depth, frames, threads):
     """The oracle (a port of the kfusion C++ path) timed on this box's host cores on the first frames."""
     from oracle import kf_ref
@@ -263,6 +275,7 @@ def main():
             a_hip = ate(est[:n_cpu], gt[:n_cpu], ts[:n_cpu], ts[:n_cpu])["rmse"] if est is not None else None
             result["cpu_baseline"] = {
                 "value": fps_cpu, "unit": "frames/s", "cores": threads, "kind": "port",
+                "cpu_model": cpu_model(), "host_cpus": os.cpu_count(),
                 "sample": "first %d frames of the same stream (same config) through the CPU oracle, OpenMP" % n_cpu,
                 "phase_seconds": {"preprocessing": phases[0], "tracking": phases[1], "integration": phases[2],
                                   "raycasting": phases[3]},
