@@ -195,7 +195,7 @@ def main():
     zs = kf.cfg.slab if kf.cfg.slab != (0, 0) else (0, V)
     planes = min(zs[1] + 2, V) - max(zs[0] - 2, 0) if zslab else V
     alg_bytes = 8.0 * V * V * planes               # 4 B read + 4 B written per voxel of this device's planes
-    achieved = alg_bytes / t_int / 1e9 if integ_ms.size else float("nan")
+    achieved = alg_bytes / t_int / 1e9 if integ_ms.size else None
 
     # accuracy on the forward part of the stream (ground truth is known for the synthetic camera)
     n_fwd = min(total, n_unique)
@@ -240,7 +240,7 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": "KFusion 640x480 depth (TUM fr1 intrinsics), %d^3 TSDF over 8 m, ICP 10/5/4, "
-                            "integration-rate 2, synthetic room stream (configs[1])" % V,
+                            "integration-rate 2, synthetic room stream%s" % (V, " (configs[1])" if (V == 512 and a.csr == 1) else ""),
                 "compute_size": "%dx%d" % cfg.compute_size, "volume": V,
                 "parallelism": ("one sequence, volume in %d z-slabs, raycast segments all-gathered (%s)" % (world, a.backend)
                                 if zslab else "%d sequence(s) per GPU (replicas, no collective)" % (1 + len(extra))

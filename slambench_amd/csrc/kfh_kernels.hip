@@ -9,6 +9,7 @@
 
 #include <cmath>
 #include <cstdlib>
+#include <type_traits>
 
 namespace kfh {
 
@@ -1866,7 +1867,7 @@ __device__ inline float bcast_lane(float v, int src) {
 // Two x-adjacent voxels fetched with one 8-byte load (the volume is only 4-byte aligned at odd x).
 // The empty asm makes the whole 64-bit value live, so the load is not narrowed into two 2-byte loads.
 typedef unsigned long long u64_align4 __attribute__((aligned(4)));
-template <bool POW2, bool OFF32>
+template <bool POW2, int OFFW>
 struct VolDev {
     const short2 *data;
     int sx, sy, sz;
@@ -1881,8 +1882,11 @@ struct VolDev {
     // POW2: log2 of sx, of sx * sy, of bgx and of bgx * bgy (index arithmetic by shifts: a 32-bit integer
     // multiply issues at a quarter of the rate of a shift)
     int lsx, lsxy, lbgx, lbgxy;
-    // OFF32: the volume is smaller than 4 GiB, so byte offsets fit 32 bits and loads use base + 32-bit offset
-    // addressing instead of a 64-bit address per lane
+    // OFFW == 0: the stored planes take less than 4 GiB, so byte offsets fit 32 bits and loads use base + 32-bit
+    // offset addressing instead of a 64-bit address per lane.  OFFW == 1: voxel numbers still fit 32 bits (up to
+    // 16 GiB; 1024^3).  OFFW == 2: voxel numbers are 64 bits wide (2048^3 on one device is 34 GB).
+    static constexpr bool OFF32 = OFFW == 0;
+    typedef typename std::conditional<OFFW == 2, unsigned long long, unsigned>::type Off;
 
     // index of the brick whose mark covers every tap of a sample at pos: the taps lie in [c, c + 1] per axis,
     // c = max(floor(scaled position), 0)
@@ -1901,12 +1905,12 @@ struct VolDev {
                    (pos.z * (float)sz / dz) - 0.5f);
     }
     __device__ inline unsigned row(int y) const { return POW2 ? (unsigned)y << lsx : (unsigned)y * (unsigned)sx; }
-    __device__ inline unsigned plane(int z) const {
+    __device__ inline Off plane(int z) const {
         z = min(max(z, zs0), zs1 - 1) - zs0;
-        return POW2 ? (unsigned)z << lsxy : (unsigned)z * (unsigned)(sx * sy);
+        return POW2 ? (Off)z << lsxy : (Off)z * (Off)(sx * sy);
     }
     // address of voxel number o
-    __device__ inline const short2 *at(unsigned o) const {
+    __device__ inline const short2 *at(Off o) const {
         if (OFF32) return reinterpret_cast<const short2 *>(reinterpret_cast<const char *>(data) + (o << 2));
         return data + o;
     }
@@ -1915,7 +1919,7 @@ struct VolDev {
     // several samples in flight before it consumes any of them.  lx and ux are either equal or adjacent,
     // so each of the four (y, z) rows needs one 8-byte fetch at x0 = min(lx, sx - 2).
     struct Tap {
-        unsigned o00, o10, o01, o11;   // voxel offsets of the four rows at x0
+        Off o00, o10, o01, o11;        // voxel offsets of the four rows at x0
         f3 f;                          // interpolation fractions
         bool l_second, u_second;       // lower / upper x tap is the second voxel of the pair
     };
@@ -1932,7 +1936,8 @@ struct VolDev {
         const int x0 = min(lx, sx - 2);
         t.l_second = lx != x0;
         t.u_second = ux != x0;
-        const unsigned rl = row(ly), ru = row(uy), pl = plane(lz), pu = plane(uz);
+        const unsigned rl = row(ly), ru = row(uy);
+        const Off pl = plane(lz), pu = plane(uz);
         t.o00 = (unsigned)x0 + rl + pl;
         t.o10 = (unsigned)x0 + ru + pl;
         t.o01 = (unsigned)x0 + rl + pu;
@@ -2025,8 +2030,8 @@ struct VolDev {
 };
 
 // Ray through pixel (x, y) and its parameter range inside the (slab of the) volume and [near, far].
-template <bool POW2, bool OFF32>
-__device__ inline void ray_setup(const VolDev<POW2, OFF32> &vol, const Mat4 &view, int x, int y, float zc0, float zc1,
+template <bool POW2, int OFFW>
+__device__ inline void ray_setup(const VolDev<POW2, OFFW> &vol, const Mat4 &view, int x, int y, float zc0, float zc1,
                                  float near_plane, float far_plane, f3 &direction, float &tnear, float &tfar) {
     const f3 origin = mk3(view.m[3], view.m[7], view.m[11]);
     direction = rotate(view, mk3((float)x, (float)y, 1.f));
@@ -2046,8 +2051,8 @@ __device__ inline void ray_setup(const VolDev<POW2, OFF32> &vol, const Mat4 &vie
 // End of a ray: `hit` says the march stopped at a negative sample f_tt at parameter t, reached with step
 // `stepsize` from the sample at t_prev.  Interpolates the zero crossing, evaluates the normal and writes
 // the pixel of every output map.
-template <bool POW2, bool OFF32>
-__device__ inline void finish_ray(const VolDev<POW2, OFF32> &vol, f3 origin, f3 direction, bool hit, float t, float t_prev,
+template <bool POW2, int OFFW>
+__device__ inline void finish_ray(const VolDev<POW2, OFFW> &vol, f3 origin, f3 direction, bool hit, float t, float t_prev,
                                   float stepsize, float f_tt, int o, float4 *__restrict__ vertex,
                                   float4 *__restrict__ normal, float *__restrict__ ray_t,
                                   float4 *__restrict__ ref_tn) {
@@ -2092,10 +2097,10 @@ struct RayTask {
 // samples fetched together (their positions only depend on the current step size; a step-size change
 // discards the rest of the batch).  A wavefront stops after RAY_MAX_ROUNDS batches, or when few of its
 // rays are still alive, and appends those rays to the task list of the second pass.
-template <bool POW2, bool OFF32>
+template <bool POW2, int OFFW>
 __global__ __launch_bounds__(256, 5) void k_raycast_march(float4 *__restrict__ vertex, float4 *__restrict__ normal,
                                                        float *__restrict__ ray_t, float4 *__restrict__ ref_tn,
-                                                       int w, int h, VolDev<POW2, OFF32> vol, float zc0, float zc1,
+                                                       int w, int h, VolDev<POW2, OFFW> vol, float zc0, float zc1,
                                                        const Mat4 *__restrict__ view_p, float near_plane,
                                                        float far_plane, float step, float largestep,
                                                        RayTask *__restrict__ tasks, unsigned *task_count,
@@ -2125,7 +2130,7 @@ __global__ __launch_bounds__(256, 5) void k_raycast_march(float4 *__restrict__ v
         } else {
             const auto tap = vol.prep(p0);
             const auto raw = vol.fetch(tap);
-            marching = VolDev<POW2, OFF32>::min_tsdf(raw) > 0 ? true : vol.combine(tap, raw) > 0;
+            marching = VolDev<POW2, OFFW>::min_tsdf(raw) > 0 ? true : vol.combine(tap, raw) > 0;
         }
     }
 
@@ -2147,7 +2152,7 @@ __global__ __launch_bounds__(256, 5) void k_raycast_march(float4 *__restrict__ v
             tk[0] = t;
 #pragma unroll
             for (int k = 1; k < RAY_BATCH; ++k) tk[k] = tk[k - 1] + stepsize;
-            typename VolDev<POW2, OFF32>::TapData raw[RAY_BATCH];
+            typename VolDev<POW2, OFFW>::TapData raw[RAY_BATCH];
 #pragma unroll
             for (int k = 0; k < RAY_BATCH; ++k) {
                 const float ts = tk[k] < tfar ? tk[k] : t;      // never sample past the far bound
@@ -2177,7 +2182,7 @@ __global__ __launch_bounds__(256, 5) void k_raycast_march(float4 *__restrict__ v
                 bool need[RAY_BATCH], any_need = false;
 #pragma unroll
                 for (int k = 0; k < RAY_BATCH; ++k) {
-                    const int mn = VolDev<POW2, OFF32>::min_tsdf(raw[k]);
+                    const int mn = VolDev<POW2, OFFW>::min_tsdf(raw[k]);
                     need[k] = !skip[k] && (fine ? mn < 0 : mn < RAY_COARSE_SAFE);
                     any_need = any_need || need[k];
                 }
@@ -2272,10 +2277,10 @@ __global__ __launch_bounds__(256, 5) void k_raycast_march(float4 *__restrict__ v
 // them), and the first lane in step order that meets a loop exit or a step-size change decides.  Long
 // rays (grazing a surface with the fine step) thus take a sixteenth of the dependent round trips, and
 // the task list spreads them over the whole device instead of the few tiles they come from.
-template <bool POW2, bool OFF32, int RAY_TAIL_LANES>
+template <bool POW2, int OFFW, int RAY_TAIL_LANES>
 __global__ __launch_bounds__(256) void k_raycast_tail(float4 *__restrict__ vertex, float4 *__restrict__ normal,
                                                       float *__restrict__ ray_t, float4 *__restrict__ ref_tn, int w,
-                                                      int h, VolDev<POW2, OFF32> vol, float zc0, float zc1,
+                                                      int h, VolDev<POW2, OFFW> vol, float zc0, float zc1,
                                                       const Mat4 *__restrict__ view_p, float near_plane,
                                                       float far_plane, float step, float largestep,
                                                       const RayTask *__restrict__ tasks,
@@ -2308,7 +2313,7 @@ __global__ __launch_bounds__(256) void k_raycast_tail(float4 *__restrict__ verte
             const bool valid = tk < tfar;
             const auto tap = vol.prep(origin + direction * (valid ? tk : bt));
             const auto raw = vol.fetch(tap);
-            const int mn = VolDev<POW2, OFF32>::min_tsdf(raw);
+            const int mn = VolDev<POW2, OFFW>::min_tsdf(raw);
             const bool need = go && valid && (fine ? mn < 0 : mn < RAY_COARSE_SAFE);
             float f = 1.0f;
             if (need) f = vol.combine(tap, raw);
@@ -2351,12 +2356,12 @@ __global__ __launch_bounds__(256) void k_raycast_tail(float4 *__restrict__ verte
 static unsigned long long *g_raycast_debug = nullptr;   // diagnostics buffer, [blocks][4 waves][4]
 void set_raycast_debug(unsigned long long *d_buffer) { g_raycast_debug = d_buffer; }
 
-template <bool POW2, bool OFF32>
+template <bool POW2, int OFFW>
 static hipError_t launch_raycast_t(float4 *vertex, float4 *normal, float *ray_t, float4 *ref_tn, int w, int h,
                                    const short2 *vol, const int res[3], const float dim[3], int z0, int z1,
                                    const Mat4 *view, float near_plane, float far_plane, float step, float largestep,
                                    void *tasks, unsigned *task_count, const unsigned char *bricks, hipStream_t s) {
-    VolDev<POW2, OFF32> v;
+    VolDev<POW2, OFFW> v;
     v.data = vol;
     v.bricks = bricks;
     v.bgx = (res[0] + 7) / 8;
@@ -2386,18 +2391,18 @@ static hipError_t launch_raycast_t(float4 *vertex, float4 *normal, float *ray_t,
     static const int max_rounds = std::getenv("KFH_RAY_ROUNDS") ? std::atoi(std::getenv("KFH_RAY_ROUNDS")) : RAY_MAX_ROUNDS;
     static const int few = std::getenv("KFH_RAY_FEW") ? std::atoi(std::getenv("KFH_RAY_FEW")) : RAY_FEW;
     static const int tail_lanes = std::getenv("KFH_RAY_TAIL_LANES") ? std::atoi(std::getenv("KFH_RAY_TAIL_LANES")) : 32;
-    hipLaunchKernelGGL((k_raycast_march<POW2, OFF32>), grid, dim3(256), 0, s, vertex, normal, ray_t, ref_tn, w, h, v, zc0, zc1,
+    hipLaunchKernelGGL((k_raycast_march<POW2, OFFW>), grid, dim3(256), 0, s, vertex, normal, ray_t, ref_tn, w, h, v, zc0, zc1,
                        view, near_plane, far_plane, step, largestep, static_cast<RayTask *>(tasks), task_count,
                        max_rounds, few, g_raycast_debug);
     const RayTask *ct = static_cast<const RayTask *>(tasks);
     if (tail_lanes == 64)
-        hipLaunchKernelGGL((k_raycast_tail<POW2, OFF32, 64>), dim3(RAY_TAIL_BLOCKS * 2), dim3(256), 0, s, vertex, normal, ray_t,
+        hipLaunchKernelGGL((k_raycast_tail<POW2, OFFW, 64>), dim3(RAY_TAIL_BLOCKS * 2), dim3(256), 0, s, vertex, normal, ray_t,
                            ref_tn, w, h, v, zc0, zc1, view, near_plane, far_plane, step, largestep, ct, task_count);
     else if (tail_lanes == 32)
-        hipLaunchKernelGGL((k_raycast_tail<POW2, OFF32, 32>), dim3(RAY_TAIL_BLOCKS), dim3(256), 0, s, vertex, normal, ray_t,
+        hipLaunchKernelGGL((k_raycast_tail<POW2, OFFW, 32>), dim3(RAY_TAIL_BLOCKS), dim3(256), 0, s, vertex, normal, ray_t,
                            ref_tn, w, h, v, zc0, zc1, view, near_plane, far_plane, step, largestep, ct, task_count);
     else
-        hipLaunchKernelGGL((k_raycast_tail<POW2, OFF32, 16>), dim3(RAY_TAIL_BLOCKS), dim3(256), 0, s, vertex, normal, ray_t,
+        hipLaunchKernelGGL((k_raycast_tail<POW2, OFFW, 16>), dim3(RAY_TAIL_BLOCKS), dim3(256), 0, s, vertex, normal, ray_t,
                            ref_tn, w, h, v, zc0, zc1, view, near_plane, far_plane, step, largestep, ct, task_count);
     return hipGetLastError();
 }
@@ -2417,11 +2422,16 @@ hipError_t launch_raycast(float4 *vertex, float4 *normal, float *ray_t, float4 *
         if (!dim_pow2 || !res_pow2 || res[i] < 2) pow2 = false;
     }
     const int stored = (z0 == 0 && z1 == res[2]) ? res[2] : (z1 + 2 < res[2] ? z1 + 2 : res[2]) - (z0 - 2 > 0 ? z0 - 2 : 0);
-    const bool off32 = (double)res[0] * res[1] * stored * sizeof(short2) <= 4294967296.0 - 16.0;
+    const double stored_voxels = (double)res[0] * res[1] * stored;
+    if ((double)res[0] * res[1] > 2147483647.0) return hipErrorInvalidValue;      // a plane is indexed with 32 bits
+    const int offw = stored_voxels * sizeof(short2) <= 4294967296.0 - 16.0 ? 0 : stored_voxels <= 4294967296.0 - 4.0 ? 1 : 2;
 #define KFH_RAYCAST_ARGS vertex, normal, ray_t, ref_tn, w, h, vol, res, dim, z0, z1, view, near_plane, far_plane, step, \
                          largestep, tasks, task_count, bricks, s
-    if (pow2) return off32 ? launch_raycast_t<true, true>(KFH_RAYCAST_ARGS) : launch_raycast_t<true, false>(KFH_RAYCAST_ARGS);
-    return off32 ? launch_raycast_t<false, true>(KFH_RAYCAST_ARGS) : launch_raycast_t<false, false>(KFH_RAYCAST_ARGS);
+    if (pow2)
+        return offw == 0 ? launch_raycast_t<true, 0>(KFH_RAYCAST_ARGS)
+             : offw == 1 ? launch_raycast_t<true, 1>(KFH_RAYCAST_ARGS) : launch_raycast_t<true, 2>(KFH_RAYCAST_ARGS);
+    return offw == 0 ? launch_raycast_t<false, 0>(KFH_RAYCAST_ARGS)
+         : offw == 1 ? launch_raycast_t<false, 1>(KFH_RAYCAST_ARGS) : launch_raycast_t<false, 2>(KFH_RAYCAST_ARGS);
 #undef KFH_RAYCAST_ARGS
 }
 

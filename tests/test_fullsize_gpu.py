@@ -235,3 +235,38 @@ def test_volume_beyond_4_gib_matches_the_oracle(torch_cuda, stream):
         assert np.linalg.norm(st["pose"][:3, 3] - ref.pose[:3, 3]) < 1e-5
     ref.close()
     kf.close()
+
+
+def test_2048_cubed_on_one_device_matches_the_oracle(torch_cuda, stream):
+    """2048^3 voxels are 34 GB and fit one device: voxel NUMBERS no longer fit 32 bits (8.6e9), so the raycast
+    runs its widest addressing variant.  The oracle needs 34 GB of host memory and some seconds per frame at
+    this size, so few frames: four with the initial pose (bit-exact volume and maps), then one tracked frame."""
+    import psutil
+    if psutil.virtual_memory().available < 100 * 2 ** 30 or torch_cuda.cuda.mem_get_info()[0] < 60 * 2 ** 30:
+        pytest.skip("needs 100 GB of free host memory (oracle volume + downloaded copy) and 60 GB on the device")
+    depth, gt, ts = stream
+    cfg = KFusionConfig(input_size=(640, 480), intrinsics=TUM_FR1_DEPTH_INTRINSICS, compute_size_ratio=1,
+                        volume_resolution=(2048, 2048, 2048))
+    kf_ref.set_threads(16)
+    ref = kf_ref.KFusionRef(oracle_config(cfg))
+    kf = KFusion(cfg)
+    for i in range(4):
+        ref.process_frame(depth[i])
+        kf.process_frame(depth[i])
+    assert np.array_equal(kf.pose, ref.pose)
+    assert np.array_equal(kf.download(native.BUF_MODEL_VERTEX)[..., :3], ref.model_vertex())
+    hit = ref.model_normal()[..., 0] != -2
+    assert hit.mean() > 0.8
+    assert np.array_equal(kf.download(native.BUF_MODEL_NORMAL)[..., :3][hit], ref.model_normal()[hit])
+    got, want = kf.download(native.BUF_VOLUME), ref.volume()
+    assert int(got[..., 1].max()) == 4                      # four depth maps fused
+    for z in range(0, 2048, 256):
+        assert np.array_equal(got[z:z + 256], want[z:z + 256]), z
+    del got, want
+    flags = ref.process_frame(depth[4])
+    kf.process_frame(depth[4])
+    st = kf.status(4)
+    assert st["tracked"] and bool(flags & 1)
+    assert np.linalg.norm(st["pose"][:3, 3] - ref.pose[:3, 3]) < 1e-5
+    ref.close()
+    kf.close()
