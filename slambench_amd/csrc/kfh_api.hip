@@ -127,7 +127,8 @@ int validate_config(const kfh_config *c) {
     KFH_REQUIRE(c->fx != 0.f && c->fy != 0.f, "focal lengths must be non-zero");
     KFH_REQUIRE(c->depth_divisor > 0.f, "depth_divisor must be positive");
     for (int i = 0; i < 3; ++i) {
-        KFH_REQUIRE(c->vol_res[i] > 0 && c->vol_res[i] <= 4096, "vol_res[%d]=%d out of range", i, c->vol_res[i]);
+        // two voxels per axis at least: a trilinear sample reads pairs of x-adjacent voxels
+        KFH_REQUIRE(c->vol_res[i] >= 2 && c->vol_res[i] <= 4096, "vol_res[%d]=%d out of range [2, 4096]", i, c->vol_res[i]);
         KFH_REQUIRE(c->vol_dim[i] > 0.f, "vol_dim[%d] must be positive", i);
         KFH_REQUIRE(c->pyramid[i] >= 0 && c->pyramid[i] <= 64, "pyramid[%d]=%d out of range", i, c->pyramid[i]);
     }

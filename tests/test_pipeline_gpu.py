@@ -252,10 +252,17 @@ def test_tuning_switches_do_not_change_results(torch_cuda):
     (8, (96, 96, 96), (640, 480), (8.0, 8.0, 8.0)),             # 80 x 60 compute image: partial tiles everywhere
     (1, (100, 120, 90), (320, 240), (8.0, 8.0, 8.0)),           # no power of two in the volume, anisotropic voxels
     (2, (160, 128, 144), (640, 480), (6.0, 7.0, 8.0)),          # non-cubic metric size
+    (1, (256, 256, 256), (1280, 960), (8.0, 8.0, 8.0)),         # four times the pixels of the usual sensor
+    (1, (256, 256, 256), (512, 424), (8.0, 8.0, 8.0)),          # a time-of-flight sensor's format: 53 rows of tiles
+    (1, (192, 192, 192), (1024, 1024), (8.0, 8.0, 8.0)),        # square
+    (1, (8, 8, 8), (160, 120), (8.0, 8.0, 8.0)),                # one brick of metre-sized voxels: nothing can track
+    (1, (4, 6, 2), (32, 24), (8.0, 8.0, 8.0)),                  # the smallest sizes the interface accepts
 ])
 def test_odd_shapes_match_oracle(torch_cuda, csr, res, size, vol_size):
     from slambench_amd.config import ICL_NUIM_INTRINSICS
-    intr = tuple(v * size[0] / 640 for v in ICL_NUIM_INTRINSICS)
+    fx, fy, cx, cy = ICL_NUIM_INTRINSICS
+    # the usual field of view at any format: focal lengths follow the width, the centre sits in the middle
+    intr = (fx * size[0] / 640, fy * size[0] / 640, cx * size[0] / 640, cy * size[1] / 480)
     centre = tuple(0.5 * v for v in vol_size)
     cfg = KFusionConfig(input_size=size, intrinsics=intr, compute_size_ratio=csr, volume_resolution=res,
                         volume_size=vol_size, volume_direction=centre)
@@ -266,4 +273,11 @@ def test_odd_shapes_match_oracle(torch_cuda, csr, res, size, vol_size):
         want = flags_ref[f]
         assert (st["tracked"], st["integrated"], st["raycasted"]) == (bool(want & 1), bool(want & 2), bool(want & 4)), f
         assert np.linalg.norm(st["pose"][:3, 3] - poses_ref[f][:3, 3]) < 1e-4, f
+    if not any(f & 1 for f in flags_ref):
+        # the pose never moved: both sides fused and raycast identical inputs, so every bit agrees
+        assert np.array_equal(kf.download(native.BUF_VOLUME), ref.volume())
+        assert np.array_equal(kf.download(native.BUF_MODEL_VERTEX)[..., :3], ref.model_vertex())
+        hit = ref.model_normal()[..., 0] != -2
+        assert np.array_equal(kf.download(native.BUF_MODEL_NORMAL)[..., :3][hit], ref.model_normal()[hit])
+        assert np.array_equal(kf.download(native.BUF_MODEL_NORMAL)[..., 0] == -2, ~hit)
     kf.close()
