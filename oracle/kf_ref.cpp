@@ -714,6 +714,7 @@ struct kfr_context {
     std::vector<int16_t> volume;
     float reduction[8 * 32];
     int tracked;
+    int icp_iterations;      /* track + reduce passes of the last frame (all levels) */
 };
 
 kfr_context *kfr_create(const kfr_config *cfg) {
@@ -782,6 +783,7 @@ int kfr_process_frame(kfr_context *c, const uint16_t *depth, double *phase_secon
             kfr_vertex2normal(c->in_normal[l].data(), c->in_vertex[l].data(), w >> l, h >> l);
         }
         c->old_pose = c->pose;
+        c->icp_iterations = 0;
         const M4 project_reference =
             mat_mul(camera_matrix(c->k[0], c->k[1], c->k[2], c->k[3]), mat_inverse(c->raycast_pose));
         for (int level = 2; level >= 0; --level) {
@@ -791,6 +793,7 @@ int kfr_process_frame(kfr_context *c, const uint16_t *depth, double *phase_secon
                           c->in_normal[level].data(), lw, lh, c->vertex.data(), c->normal.data(), w, h,
                           &c->pose.r[0].x, &project_reference.r[0].x, 0.1f, 0.8f);
                 kfr_reduce(c->reduction, c->tracking_result.data(), w, lw, lh);
+                c->icp_iterations++;
                 if (kfr_update_pose(&c->pose.r[0].x, c->reduction, cfg.icp_threshold)) break;
             }
         }
@@ -855,6 +858,7 @@ const float *kfr_model_vertex(const kfr_context *c) { return c->vertex.data(); }
 const float *kfr_model_normal(const kfr_context *c) { return c->normal.data(); }
 const int16_t *kfr_volume(const kfr_context *c) { return c->volume.data(); }
 const float *kfr_reduction(const kfr_context *c) { return c->reduction; }
+int kfr_icp_iterations(const kfr_context *c) { return c->icp_iterations; }
 const kfr_track_data *kfr_tracking_result(const kfr_context *c) { return c->tracking_result.data(); }
 
 }  /* extern "C" */

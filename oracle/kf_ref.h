@@ -104,6 +104,7 @@ const float   *kfr_model_vertex(const kfr_context *c);
 const float   *kfr_model_normal(const kfr_context *c);
 const int16_t *kfr_volume(const kfr_context *c);
 const float   *kfr_reduction(const kfr_context *c);
+int kfr_icp_iterations(const kfr_context *c);                       /* track + reduce passes of the last tracked-rate frame */
 const kfr_track_data *kfr_tracking_result(const kfr_context *c);   /* [h][w] of the compute size, last iteration run */
 
 #ifdef __cplusplus

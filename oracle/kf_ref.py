@@ -71,6 +71,8 @@ def lib():
         for name in ("kfr_scaled_depth", "kfr_input_vertex", "kfr_input_normal"):
             getattr(L, name).restype = C.c_void_p
             getattr(L, name).argtypes = [C.c_void_p, C.c_int]
+        L.kfr_icp_iterations.restype = C.c_int
+        L.kfr_icp_iterations.argtypes = [C.c_void_p]
         L.kfr_set_threads.restype = C.c_int
         L.kfr_set_threads.argtypes = [C.c_int]
         L.kfr_update_pose.restype = C.c_int
@@ -341,6 +343,10 @@ class KFusionRef:
 
     def reduction(self):
         return self._view(lib().kfr_reduction(self._c), (8, 32), np.float32)[0]
+
+    def icp_iterations(self):
+        """Track + reduce passes of the last frame on which tracking ran."""
+        return lib().kfr_icp_iterations(self._c)
 
     def tracking_result(self):
         return self._view(lib().kfr_tracking_result(self._c), (self.h, self.w), TRACK_DTYPE)

@@ -127,6 +127,52 @@ def test_tracking_rate_and_filtered_integration(torch_cuda):
     kf.close()
 
 
+@pytest.mark.parametrize("kw,noise", [
+    (dict(icp_threshold=2e-3), False),                # levels stop early: fewer than 19 iterations per frame
+    (dict(icp_threshold=1e-1), True),                 # every level stops after its first iteration
+    (dict(pyramid=(3, 0, 2)), True),                  # a level without iterations
+    (dict(pyramid=(0, 0, 6)), True),                  # only the coarsest level runs: its pixel count is below
+                                                      #   15 % of the full image, so every frame is rejected
+    (dict(pyramid=(20, 10, 8)), True),                # more iterations than the defaults
+    (dict(mu=0.05, integration_rate=1, res=256), True),   # thin band (finer voxels to match), fuse every frame
+    (dict(mu=0.3, integration_rate=4), True),         # thick band, coarse steps of 0.225 m
+])
+def test_parameter_variations_match_oracle(torch_cuda, kw, noise):
+    """The plugin's parameters away from their defaults: flags, the number of ICP iterations actually run and
+    the poses follow the oracle."""
+    n = 16
+    kw = dict(kw)
+    res = kw.pop("res", 128)
+    cfg = KFusionConfig(compute_size_ratio=2, volume_resolution=(res, res, res), **kw)
+    depth, gt, ts = synth.make_sequence(n, seed=4, noise=noise)
+    ref = kf_ref.KFusionRef(oracle_config(cfg))
+    kf = KFusion(cfg)
+    iterations = []
+    for i in range(n):
+        want = ref.process_frame(depth[i])
+        kf.process_frame(depth[i])
+        st = kf.status(i)
+        assert (st["tracked"], st["integrated"], st["raycasted"]) == (bool(want & 1), bool(want & 2), bool(want & 4)), i
+        assert np.linalg.norm(st["pose"][:3, 3] - ref.pose[:3, 3]) < (1e-3 if kw.get("mu") == 0.3 else 1e-4), i
+        if i >= 4:          # tracking starts with the first raycast
+            # With the default threshold a level ends early when the update falls below 1e-5, where it hovers at
+            # the level of the rounding of the sums: which iteration first dips under the threshold depends on
+            # the summation order, the pose it ends with does not (the assertion above).  A coarse threshold is
+            # crossed with a wide margin and the counts are equal.
+            slack = 0 if "icp_threshold" in kw else 4 if kw.get("pyramid") == (20, 10, 8) else 2
+            assert abs(st["icp_iterations"] - ref.icp_iterations()) <= slack, i
+            iterations.append(st["icp_iterations"])
+    assert any(kf.status(i)["tracked"] for i in range(4, n)) == (kw.get("pyramid") != (0, 0, 6))
+    if "icp_threshold" in kw:
+        assert max(iterations) < 19
+    if kw.get("icp_threshold") == 1e-1:
+        assert set(iterations) == {3}
+    if "pyramid" in kw:
+        assert max(iterations) <= sum(kw["pyramid"])
+    ref.close()
+    kf.close()
+
+
 def test_reset_and_set_pose(torch_cuda):
     cfg = KFusionConfig(compute_size_ratio=4, volume_resolution=(128, 128, 128))
     depth, gt, ts = synth.make_sequence(6, seed=1)
