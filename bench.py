@@ -41,6 +41,9 @@ def parse_args():
     ap.add_argument("--sequences-per-gpu", type=int, default=1,
                     help="independent sequences (contexts, one stream each) interleaved on every GPU; the "
                          "default 1 is the benchmark, more measures how many sweep points one GPU can carry")
+    ap.add_argument("--host-threads", action="store_true",
+                    help="with --sequences-per-gpu S: one host thread per sequence instead of one thread that "
+                         "interleaves them (the library calls release the interpreter lock)")
     ap.add_argument("--host-frames", action="store_true",
                     help="also time the stream with frames handed over in host memory (one H2D copy per frame); "
                          "reported as pcie_inclusive_frames_per_s, never as value")
@@ -175,10 +178,29 @@ def main():
         step(order[i])
     sync_all()
     barrier()
-    t0 = time.perf_counter()
-    for i in range(untimed, total):
-        step(order[i])
-    sync_all()
+    if a.host_threads and extra:
+        import threading
+        seqs = [(kf, frame_ptrs)] + [(kq, ptrs) for kq, _, ptrs in extra]
+        go = threading.Barrier(len(seqs) + 1)
+
+        def run(k, ptrs):
+            go.wait()
+            for i in range(untimed, total):
+                k.process_frame(ptrs[order[i]])
+            k.sync()
+
+        workers = [threading.Thread(target=run, args=sq) for sq in seqs]
+        for t in workers:
+            t.start()
+        go.wait()
+        t0 = time.perf_counter()
+        for t in workers:
+            t.join()
+    else:
+        t0 = time.perf_counter()
+        for i in range(untimed, total):
+            step(order[i])
+        sync_all()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if world > 1:
