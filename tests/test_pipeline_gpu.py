@@ -327,3 +327,70 @@ def test_odd_shapes_match_oracle(torch_cuda, csr, res, size, vol_size):
         assert np.array_equal(kf.download(native.BUF_MODEL_NORMAL)[..., :3][hit], ref.model_normal()[hit])
         assert np.array_equal(kf.download(native.BUF_MODEL_NORMAL)[..., 0] == -2, ~hit)
     kf.close()
+
+
+def test_camera_outside_the_volume(torch_cuda):
+    """The camera starts half a metre in front of a 3 m volume and looks into it: every ray enters through a face
+    (its march starts at the entry distance, not at the near plane), part of the scene lies outside the volume,
+    and integration sees voxels from outside.  Flags and poses follow the oracle; tracking works."""
+    cfg = KFusionConfig(compute_size_ratio=2, volume_resolution=(128, 128, 128), volume_size=(3.0, 3.0, 3.0),
+                        volume_direction=(1.5, 1.5, -0.5))
+    depth, gt, ts = synth.make_sequence(14, seed=6, noise=True)
+    ref, kf, flags_ref, poses_ref = _run_both(cfg, depth)
+    for f in range(14):
+        st = kf.status(f)
+        want = flags_ref[f]
+        assert (st["tracked"], st["integrated"], st["raycasted"]) == (bool(want & 1), bool(want & 2), bool(want & 4)), f
+        assert np.linalg.norm(st["pose"][:3, 3] - poses_ref[f][:3, 3]) < 1e-4, f
+    assert sum(bool(f & 1) for f in flags_ref) >= 8
+    hit = ref.model_normal()[..., 0] != -2
+    assert 0.2 < hit.mean() < 0.95                       # part of the view ends outside the volume
+    got_hit = kf.download(native.BUF_MODEL_NORMAL)[..., 0] != -2
+    assert (got_hit != hit).mean() < 2e-3
+    kf.close()
+
+
+def _rotation(axis, degrees):
+    a = np.asarray(axis, np.float64)
+    a = a / np.linalg.norm(a)
+    t = np.radians(degrees)
+    Kx = np.array([[0, -a[2], a[1]], [a[2], 0, -a[0]], [-a[1], a[0], 0]])
+    return np.eye(3) + np.sin(t) * Kx + (1 - np.cos(t)) * (Kx @ Kx)
+
+
+@pytest.mark.parametrize("axis,degrees", [((0, 1, 0), 90), ((0, 1, 0), 180), ((1, 0, 0), -90), ((0, 0, 1), 180),
+                                          ((1, 1, 0), 135), ((0.3, -0.5, 0.8), 217)])
+def test_any_camera_orientation(torch_cuda, axis, degrees):
+    """The reference starts every sequence with an identity rotation; a caller of the C interface may set any
+    pose.  The frustum planning of the integration (which boxes can be seen, which lie behind the seen surface),
+    the brick marks and the slab test of the raycast must not depend on the camera looking along +z: the stream
+    is fused and raycast from a rotated initial pose, bit for bit as the oracle does it, and then tracked."""
+    cfg = KFusionConfig(compute_size_ratio=2, volume_resolution=(128, 128, 128))
+    depth, gt, ts = synth.make_sequence(10, seed=8, noise=True)
+    pose = np.eye(4, dtype=np.float32)
+    pose[:3, :3] = _rotation(axis, degrees).astype(np.float32)
+    pose[:3, 3] = (4.1, 3.9, 4.05)
+    ref = kf_ref.KFusionRef(oracle_config(cfg))
+    kf = KFusion(cfg)
+    ref.set_pose(pose)
+    kf.set_pose(pose)
+    for i in range(4):
+        ref.process_frame(depth[i])
+        kf.process_frame(depth[i])
+    assert np.array_equal(kf.pose, pose) and np.array_equal(ref.pose, pose)
+    vol = ref.volume()
+    assert (vol[..., 1] > 0).mean() > 0.005
+    assert np.array_equal(kf.download(native.BUF_VOLUME), vol)
+    hit = ref.model_normal()[..., 0] != -2
+    assert hit.mean() > 0.8
+    assert np.array_equal(kf.download(native.BUF_MODEL_VERTEX)[..., :3], ref.model_vertex())
+    assert np.array_equal(kf.download(native.BUF_MODEL_NORMAL)[..., :3][hit], ref.model_normal()[hit])
+    for i in range(4, 10):
+        want = ref.process_frame(depth[i])
+        kf.process_frame(depth[i])
+        st = kf.status(i)
+        assert (st["tracked"], st["integrated"], st["raycasted"]) == (bool(want & 1), bool(want & 2), bool(want & 4)), i
+        assert st["tracked"], i
+        assert np.linalg.norm(st["pose"][:3, 3] - ref.pose[:3, 3]) < 1e-4, i
+    ref.close()
+    kf.close()
