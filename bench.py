@@ -263,7 +263,7 @@ def main():
             "untimed_frames": untimed,
             "ms_per_step": elapsed / a.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if zslab else "weak",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
