@@ -23,7 +23,11 @@
  *     memory; an invalid normal has x == -2;
  *   - the TSDF volume is short2 per voxel (x: tsdf * 32766, y: weight), index x + y*X + z*X*Y;
  *   - pointers named d_* are device pointers, h_* host pointers; `stream` is a hipStream_t
- *     passed as void* (NULL = the default stream).
+ *     passed as void* (NULL = the default stream);
+ *   - a context belongs to the device that was current in kfh_create; every kfh_* call on it makes
+ *     that device current for its own duration and restores the caller's, so contexts of several
+ *     devices can be driven from one thread or from one thread each.  Calls on ONE context must not
+ *     overlap; calls on different contexts may (kfh_last_error() is per thread).
  */
 #ifndef KFUSION_HIP_H_
 #define KFUSION_HIP_H_

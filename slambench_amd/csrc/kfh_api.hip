@@ -117,6 +117,21 @@ constexpr int KFH_TIMING_RING = 512;
 
 namespace {
 
+// Entry points may be called from any thread and with any device current: the context's device is made
+// current for the duration of the call (its streams, events and buffers belong to it) and the caller's put back.
+struct DeviceScope {
+    int previous = -1;
+    bool switched = false;
+    explicit DeviceScope(int device) {
+        if (hipGetDevice(&previous) == hipSuccess && previous != device) switched = hipSetDevice(device) == hipSuccess;
+    }
+    ~DeviceScope() {
+        if (switched) (void)hipSetDevice(previous);
+    }
+    DeviceScope(const DeviceScope &) = delete;
+    DeviceScope &operator=(const DeviceScope &) = delete;
+};
+
 int validate_config(const kfh_config *c) {
     KFH_REQUIRE(c != nullptr, "config is NULL");
     KFH_REQUIRE(c->input_width > 0 && c->input_height > 0, "input size must be positive");
@@ -348,6 +363,7 @@ int kfh_create(const kfh_config *cfg, kfh_context **out) {
 
 int kfh_destroy(kfh_context *c) {
     if (!c) return KFH_OK;
+    DeviceScope on_device(c->device);
     if (c->pre_stream) (void)hipStreamSynchronize(c->pre_stream);
     (void)hipStreamSynchronize(c->stream);
     free_all(c);
@@ -357,11 +373,13 @@ int kfh_destroy(kfh_context *c) {
 
 int kfh_reset(kfh_context *c) {
     KFH_REQUIRE(c != nullptr, "context is NULL");
+    DeviceScope on_device(c->device);
     return init_state(c);
 }
 
 int kfh_upload_depth(kfh_context *c, const uint16_t *h_depth) {
     KFH_REQUIRE(c != nullptr && h_depth != nullptr, "NULL argument");
+    DeviceScope on_device(c->device);
     const size_t bytes = (size_t)c->cfg.input_width * c->cfg.input_height * sizeof(uint16_t);
     // The copy goes on the stream that preprocesses.  The slot's pinned buffer fed the copy of the frame before
     // the previous one and its device buffer that frame's preprocessing launch: wait for that launch only, so the
@@ -390,6 +408,7 @@ int kfh_set_depth_device(kfh_context *c, const uint16_t *d_depth) {
 
 int kfh_preprocess(kfh_context *c) {
     KFH_REQUIRE(c != nullptr, "context is NULL");
+    DeviceScope on_device(c->device);
     // With phase timing on, everything runs on the main stream so that the four phases do not overlap.
     const bool side = c->overlap && c->timing != 1;
     hipStream_t ps = side ? c->pre_stream : c->stream;
@@ -420,6 +439,7 @@ int kfh_preprocess(kfh_context *c) {
 
 int kfh_track(kfh_context *c) {
     KFH_REQUIRE(c != nullptr, "context is NULL");
+    DeviceScope on_device(c->device);
     KFH_HIP(ensure_pre_done(c));
     int total_iterations = 0;
     for (int l = 0; l < 3; ++l) total_iterations += c->cfg.pyramid[l];
@@ -473,6 +493,7 @@ static const float *tile_max_for_integrate(const kfh_context *c) {
 
 int kfh_integrate(kfh_context *c) {
     KFH_REQUIRE(c != nullptr, "context is NULL");
+    DeviceScope on_device(c->device);
     KFH_HIP(ensure_pre_done(c));
     if ((c->frame % c->cfg.integration_rate) == 0 || c->frame <= 3) {
         const float *src = c->cfg.integrate_filtered ? c->d_scaled[0] : c->d_float_depth;
@@ -499,6 +520,7 @@ static float raycast_step(const kfh_config &cfg) {
 
 int kfh_raycast(kfh_context *c) {
     KFH_REQUIRE(c != nullptr, "context is NULL");
+    DeviceScope on_device(c->device);
     if (c->frame > 2 && !c->sharded) {
         KFH_HIP(launch_raycast(c->d_vertex, c->d_normal, c->d_ray_t, c->d_ref_tn, c->w, c->h, c->d_volume,
                                c->cfg.vol_res, c->cfg.vol_dim, 0, c->cfg.vol_res[2], &c->d_ctrl->view, NEAR_PLANE, FAR_PLANE,
@@ -514,6 +536,7 @@ int kfh_raycast(kfh_context *c) {
 
 int kfh_raycast_slab(kfh_context *c) {
     KFH_REQUIRE(c != nullptr, "context is NULL");
+    DeviceScope on_device(c->device);
     if (c->frame > 2) {
         KFH_HIP(launch_raycast(c->d_vertex, c->d_normal, c->d_ray_t, nullptr, c->w, c->h, c->d_volume,
                                c->cfg.vol_res, c->cfg.vol_dim, c->cfg.slab_z0, c->cfg.slab_z1, &c->d_ctrl->view, NEAR_PLANE,
@@ -525,6 +548,7 @@ int kfh_raycast_slab(kfh_context *c) {
 
 int kfh_composite_slabs(kfh_context *c, const float *d_t, const void *d_vertex, const void *d_normal, int n_parts) {
     KFH_REQUIRE(c != nullptr && d_t && d_vertex && d_normal, "NULL argument");
+    DeviceScope on_device(c->device);
     KFH_REQUIRE(n_parts >= 1 && n_parts <= 64, "n_parts=%d out of range", n_parts);
     if (c->frame > 2) {
         KFH_HIP(launch_composite(c->d_vertex, c->d_normal, c->d_ray_t, c->d_ref_tn, d_t, static_cast<const float4 *>(d_vertex),
@@ -535,6 +559,7 @@ int kfh_composite_slabs(kfh_context *c, const float *d_t, const void *d_vertex, 
 
 int kfh_enable_track_render(kfh_context *c, int enabled) {
     KFH_REQUIRE(c != nullptr, "context is NULL");
+    DeviceScope on_device(c->device);
     const size_t npix = (size_t)c->w * c->h;
     if (enabled && !c->d_track_codes) {
         KFH_HIP(dev_alloc(&c->d_track_codes, npix));
@@ -549,6 +574,7 @@ int kfh_enable_track_render(kfh_context *c, int enabled) {
 
 int kfh_render_device(kfh_context *c, int image, const float view_pose[16], uint8_t *d_rgba) {
     KFH_REQUIRE(c != nullptr && d_rgba != nullptr, "NULL argument");
+    DeviceScope on_device(c->device);
     const int npix = c->w * c->h;
     uchar4 *out = reinterpret_cast<uchar4 *>(d_rgba);
     KFH_HIP(ensure_pre_done(c));
@@ -592,6 +618,7 @@ int kfh_render_device(kfh_context *c, int image, const float view_pose[16], uint
 
 int kfh_render(kfh_context *c, int image, const float view_pose[16], uint8_t *h_rgba, size_t bytes) {
     KFH_REQUIRE(c != nullptr && h_rgba != nullptr, "NULL argument");
+    DeviceScope on_device(c->device);
     const size_t need = (size_t)c->w * c->h * 4;
     KFH_REQUIRE(bytes >= need, "image needs %zu bytes, destination holds %zu", need, bytes);
     if (!c->d_render_rgba) KFH_HIP(dev_alloc(&c->d_render_rgba, (size_t)c->w * c->h));
@@ -603,6 +630,7 @@ int kfh_render(kfh_context *c, int image, const float view_pose[16], uint8_t *h_
 
 int kfh_end_frame(kfh_context *c) {
     KFH_REQUIRE(c != nullptr, "context is NULL");
+    DeviceScope on_device(c->device);
     KFH_HIP(ensure_pre_done(c));
     KFH_HIP(hipEventRecord(c->ev_set_free[c->cur_set], c->stream));   // this frame is done with its depth images
     c->frame++;
@@ -610,6 +638,8 @@ int kfh_end_frame(kfh_context *c) {
 }
 
 int kfh_process_frame(kfh_context *c) {
+    KFH_REQUIRE(c != nullptr, "context is NULL");
+    DeviceScope on_device(c->device);          // the calls below then find the right device current
     if (int rc = kfh_preprocess(c)) return rc;
     if (int rc = kfh_track(c)) return rc;
     if (int rc = kfh_integrate(c)) return rc;
@@ -619,6 +649,7 @@ int kfh_process_frame(kfh_context *c) {
 
 int kfh_sync(kfh_context *c) {
     KFH_REQUIRE(c != nullptr, "context is NULL");
+    DeviceScope on_device(c->device);
     KFH_HIP(hipStreamSynchronize(c->pre_stream));
     KFH_HIP(hipStreamSynchronize(c->stream));
     return KFH_OK;
@@ -626,6 +657,7 @@ int kfh_sync(kfh_context *c) {
 
 int kfh_get_pose(kfh_context *c, float pose[16]) {
     KFH_REQUIRE(c != nullptr && pose != nullptr, "NULL argument");
+    DeviceScope on_device(c->device);
     KFH_HIP(hipMemcpyAsync(pose, &c->d_ctrl->pose, sizeof(Mat4), hipMemcpyDeviceToHost, c->stream));
     KFH_HIP(hipStreamSynchronize(c->stream));
     return KFH_OK;
@@ -633,6 +665,7 @@ int kfh_get_pose(kfh_context *c, float pose[16]) {
 
 int kfh_set_pose(kfh_context *c, const float pose[16]) {
     KFH_REQUIRE(c != nullptr && pose != nullptr, "NULL argument");
+    DeviceScope on_device(c->device);
     KFH_HIP(hipMemcpyAsync(&c->d_ctrl->pose, pose, sizeof(Mat4), hipMemcpyHostToDevice, c->stream));
     KFH_HIP(hipStreamSynchronize(c->stream));
     KFH_HIP(launch_pose_derive(c->d_ctrl, c->k, 0, c->stream));
@@ -641,6 +674,7 @@ int kfh_set_pose(kfh_context *c, const float pose[16]) {
 
 int kfh_get_status(kfh_context *c, int frame, kfh_frame_status *out) {
     KFH_REQUIRE(c != nullptr && out != nullptr, "NULL argument");
+    DeviceScope on_device(c->device);
     KFH_REQUIRE(frame >= 0 && frame < c->frame && frame >= c->frame - KFH_STATUS_RING,
                 "frame %d is not in the retained window (%d frames processed)", frame, c->frame);
     KFH_HIP(hipMemcpyAsync(out, c->d_status + (frame % KFH_STATUS_RING), sizeof(kfh_frame_status),
@@ -704,6 +738,7 @@ int kfh_download(kfh_context *c, int buffer, int level, void *h_dst, size_t byte
     size_t have = 0;
     if (int rc = kfh_device_ptr(c, buffer, level, &src, &have)) return rc;
     KFH_REQUIRE(bytes <= have, "requested %zu bytes, buffer holds %zu", bytes, have);
+    DeviceScope on_device(c->device);
     KFH_HIP(hipMemcpyAsync(h_dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
     KFH_HIP(hipStreamSynchronize(c->stream));
     return KFH_OK;
@@ -717,6 +752,7 @@ int kfh_stream(kfh_context *c, void **stream) {
 
 int kfh_set_timing(kfh_context *c, int mode) {
     KFH_REQUIRE(c != nullptr, "context is NULL");
+    DeviceScope on_device(c->device);
     KFH_REQUIRE(mode >= 0 && mode <= 3, "timing mode must be 0, 1, 2 or 3");
     if (mode != 0 && !c->ev) {
         c->ev = new (std::nothrow) hipEvent_t[KFH_TIMING_RING][5]();
@@ -731,6 +767,7 @@ int kfh_set_timing(kfh_context *c, int mode) {
 
 int kfh_phase_ms_frame(kfh_context *c, int frame, float ms[4]) {
     KFH_REQUIRE(c != nullptr && ms != nullptr, "NULL argument");
+    DeviceScope on_device(c->device);
     if (!c->timing || c->timed_first < 0)
         return fail(KFH_ERR_STATE, "no frame has been processed with timing enabled");
     KFH_REQUIRE(frame >= c->timed_first && frame < c->frame && frame >= c->frame - KFH_TIMING_RING &&
@@ -749,6 +786,7 @@ int kfh_phase_ms_frame(kfh_context *c, int frame, float ms[4]) {
 
 int kfh_phase_ms(kfh_context *c, float ms[4]) {
     KFH_REQUIRE(c != nullptr, "context is NULL");
+    DeviceScope on_device(c->device);
     return kfh_phase_ms_frame(c, c->frame - 1, ms);
 }
 
@@ -785,6 +823,7 @@ int kfh_debug_solver_us(const float *h_sums32, float *us_per_update) {
 // h_out holds n_values = boxes * 4 wavefronts * 4 values + 1; the last one receives the number of boxes kept.
 int kfh_debug_integrate_stats(kfh_context *c, unsigned long long *h_out, size_t n_values) {
     KFH_REQUIRE(c != nullptr && h_out != nullptr, "NULL argument");
+    DeviceScope on_device(c->device);
     if (!icp_stamps_compiled()) return fail(KFH_ERR_STATE, "this library was built without diagnostics (make -C slambench_amd/csrc clean && make -C slambench_amd/csrc STAMPS=1)");
     unsigned long long *d = nullptr;
     KFH_HIP(hipMalloc(reinterpret_cast<void **>(&d), n_values * sizeof(unsigned long long)));
@@ -812,6 +851,7 @@ int kfh_debug_integrate_stats(kfh_context *c, unsigned long long *h_out, size_t 
 // second pass received.
 int kfh_debug_raycast_stats(kfh_context *c, unsigned long long *h_out) {
     KFH_REQUIRE(c != nullptr && h_out != nullptr, "NULL argument");
+    DeviceScope on_device(c->device);
     if (!icp_stamps_compiled()) return fail(KFH_ERR_STATE, "this library was built without diagnostics (make -C slambench_amd/csrc clean && make -C slambench_amd/csrc STAMPS=1)");
     const size_t n = (size_t)((c->w + 15) / 16) * ((c->h + 15) / 16) * 16;
     unsigned long long *d = nullptr;
@@ -838,6 +878,7 @@ int kfh_debug_raycast_stats(kfh_context *c, unsigned long long *h_out) {
 // was created with KFH_ICP_STAMPS set.
 int kfh_debug_icp_stamps(kfh_context *c, unsigned long long *h_out) {
     KFH_REQUIRE(c != nullptr && h_out != nullptr, "NULL argument");
+    DeviceScope on_device(c->device);
     if (!c->d_stamps) return fail(KFH_ERR_STATE, "context was created without KFH_ICP_STAMPS");
     if (!icp_stamps_compiled()) return fail(KFH_ERR_STATE, "this library was built without diagnostics (make -C slambench_amd/csrc clean && make -C slambench_amd/csrc STAMPS=1)");
     KFH_HIP(hipStreamSynchronize(c->stream));
