@@ -394,3 +394,35 @@ def test_any_camera_orientation(torch_cuda, axis, degrees):
         assert np.linalg.norm(st["pose"][:3, 3] - ref.pose[:3, 3]) < 1e-4, i
     ref.close()
     kf.close()
+
+
+def test_contexts_driven_from_concurrent_threads(torch_cuda):
+    """Two contexts, each driven by a host thread of its own at the same time, on different streams of the same
+    device: no state is shared between contexts, so each trajectory has the bits of a run on its own."""
+    import threading
+    cfgs = [KFusionConfig(compute_size_ratio=2, volume_resolution=(128, 128, 128)),
+            KFusionConfig(compute_size_ratio=4, volume_resolution=(96, 96, 96), mu=0.15)]
+    streams = [synth.make_sequence(40, seed=21, noise=True)[0], synth.make_sequence(40, seed=22, noise=True)[0]]
+
+    def run(cfg, depth, out):
+        kf = KFusion(cfg)
+        for d in depth:
+            kf.process_frame(d)
+        out.append((kf.trajectory(), kf.download(native.BUF_VOLUME)))
+        kf.close()
+
+    alone = []
+    for cfg, depth in zip(cfgs, streams):
+        run(cfg, depth, alone)
+    together = [[], []]
+    for rep in range(2):                       # twice: the interleaving differs from run to run
+        workers = [threading.Thread(target=run, args=(cfgs[i], streams[i], together[i])) for i in range(2)]
+        for t in workers:
+            t.start()
+        for t in workers:
+            t.join()
+    for i in range(2):
+        assert len(together[i]) == 2
+        for traj, vol in together[i]:
+            assert np.array_equal(traj, alone[i][0])
+            assert np.array_equal(vol, alone[i][1])
