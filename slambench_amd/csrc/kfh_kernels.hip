@@ -1495,7 +1495,8 @@ struct IntegrateArgs {
     const int *gate;            // device flag: 0 = this frame does not integrate
     int zchunk;
     int gx, gy, gz;             // boxes of 64 x 4 x zchunk voxels
-    unsigned *boxes;            // list of boxes that may touch the camera frustum (packed bx | by << 8 | bz << 20)
+    unsigned *boxes;            // list of box groups that may touch the camera frustum (INTEGRATE_GROUP boxes that
+                                //   follow each other in z): bx | by << 8 | group << 20 | mask of its boxes << 28
     unsigned *box_count;
     unsigned char *bricks;      // per 8^3 brick: 1 while no voxel of the brick (plus one voxel past it) went
     int bgx, bgy;               //   below RAY_COARSE_SAFE since the last reset; may be null
@@ -1592,6 +1593,7 @@ __device__ inline bool box_misses_frustum(const IntegrateArgs &a, const Mat4 &in
 // of dispatching a workgroup per box of the whole volume.
 constexpr int KFH_PLAN_TILES_PER_THREAD = 8;
 constexpr int KFH_PLAN_MAX_TILES = 256 * KFH_PLAN_TILES_PER_THREAD;     // depth tiles a plan block holds in LDS (640 x 480: 1200)
+template <int INTEGRATE_GROUP>     // boxes per work item (consecutive in z): 1, 2 or 4 (mask bits of the packed item)
 __global__ __launch_bounds__(256) void k_integrate_plan(IntegrateArgs a) {
     __shared__ float tile_max_lds[KFH_PLAN_MAX_TILES];
     __shared__ float coarse_max_lds[KFH_PLAN_MAX_TILES / 16 + 64];     // maxima of 4 x 4 tiles
@@ -1624,28 +1626,44 @@ __global__ __launch_bounds__(256) void k_integrate_plan(IntegrateArgs a) {
         }
         __syncthreads();
     }
+    // INTEGRATE_GROUP neighbouring lanes hold the boxes of one group (same x and y, consecutive in z); the first
+    // of them appends the group with the mask of its surviving boxes
     const int id = blockIdx.x * blockDim.x + threadIdx.x;
-    const int nbox = a.gx * a.gy * a.gz;
+    const int groups = (a.gz + INTEGRATE_GROUP - 1) / INTEGRATE_GROUP;
+    const int nthreads = a.gx * a.gy * groups * INTEGRATE_GROUP;
     bool keep = false;
-    int bx = 0, by = 0, bz = 0;
-    if (id < nbox) {
-        bx = id % a.gx;
-        by = (id / a.gx) % a.gy;
-        bz = id / (a.gx * a.gy);
+    int bx = 0, by = 0, g = 0;
+    const int r = id % INTEGRATE_GROUP;
+    if (id < nthreads) {
+        // x fastest, then y, then z: the lanes of a wavefront test boxes of similar depth and footprint, and
+        // neighbouring items of the list touch neighbouring rows of the volume
+        const int q = id / INTEGRATE_GROUP;
+        bx = q % a.gx;
+        by = (q / a.gx) % a.gy;
+        g = q / (a.gx * a.gy);
+        const int bz = g * INTEGRATE_GROUP + r;
         const int zc0 = max(a.z0, bz * a.zchunk), zc1 = min(a.z1, (bz + 1) * a.zchunk);
-        keep = zc0 < zc1 && !box_misses_frustum(a, inv_track, bx, by, zc0, zc1, tile_max_lds, coarse_max_lds, depth_test);
+        keep = bz < a.gz && zc0 < zc1 &&
+               !box_misses_frustum(a, inv_track, bx, by, zc0, zc1, tile_max_lds, coarse_max_lds, depth_test);
     }
     const unsigned long long m = __ballot(keep);
     if (m) {
-        const int lane = threadIdx.x & 63, first = __ffsll((long long)m) - 1;
+        const int lane = threadIdx.x & 63;
+        const unsigned gm = (unsigned)(m >> (lane & ~(INTEGRATE_GROUP - 1))) & ((1u << INTEGRATE_GROUP) - 1u);
+        const bool leader = r == 0 && gm != 0u;
+        const unsigned long long lm = __ballot(leader);
+        const int first = __ffsll((long long)lm) - 1;
         unsigned base = 0;
-        if (lane == first) base = atomicAdd(a.box_count, (unsigned)__popcll(m));
+        if (lane == first) base = atomicAdd(a.box_count, (unsigned)__popcll(lm));
         base = __builtin_amdgcn_readlane(base, first);
-        if (keep) a.boxes[base + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned)bx | ((unsigned)by << 8) | ((unsigned)bz << 20);
+        if (leader)
+            a.boxes[base + __popcll(lm & ((1ull << lane) - 1ull))] =
+                (unsigned)bx | ((unsigned)by << 8) | ((unsigned)g << 20) | (gm << 28);
     }
 }
 
 // Second launch: a workgroup takes boxes from the list; one thread per (x, y) column of the box.
+template <int INTEGRATE_GROUP>
 __global__ __launch_bounds__(256) void k_integrate(IntegrateArgs a) {
     if (!KFH_STAMPS_COMPILED) a.dbg = nullptr;      // per-wavefront statistics only in diagnostic builds
     const unsigned nbox = *a.box_count;
@@ -1665,119 +1683,128 @@ __global__ __launch_bounds__(256) void k_integrate(IntegrateArgs a) {
         unsigned dbg_cand = 0, dbg_written = 0;
         if (a.dbg) dbg_t0 = __builtin_amdgcn_s_memrealtime();
         const unsigned box = a.boxes[bi];
-        const int bx = box & 0xFF, by = (box >> 8) & 0xFFF, bz = box >> 20;
+        const int bx = box & 0xFF, by = (box >> 8) & 0xFFF, group = (box >> 20) & 0xFF;
+        const unsigned group_mask = box >> 28;
         const int x = bx * 64 + (threadIdx.x & 63);
         const int y = by * 4 + (threadIdx.x >> 6);
         const bool in_vol = x < sx && y < sy;
-        const int zc0 = max(a.z0, bz * a.zchunk);
-        const int zc1 = min(a.z1, (bz + 1) * a.zchunk);
         const f3 p0 = mk3(((float)x + 0.5f) * dimx / (float)sx, ((float)y + 0.5f) * dimy / (float)sy,
                           (0.0f + 0.5f) * dimz / (float)sz);
-        f3 pos = xform(invTrack, p0);
-        f3 cameraX = xform(K, pos);
         short2 *col = a.vol + (size_t)min(x, sx - 1) + (size_t)min(y, sy - 1) * sx;
+        // The reference accumulates the camera-space position of a column step by step from z = 0.  The same
+        // additions in the same order are replayed up to each box, two components per packed add; the boxes of a
+        // group follow each other in z, so the replay is paid once per group and carried from box to box.
+        typedef float v2f __attribute__((ext_vector_type(2)));
+        v2f acc0, acc1, acc2;
         {
-            // replay the additions of the steps below this chunk: same operations in the same order as a march
-            // from z = 0, two components per packed add
-            typedef float v2f __attribute__((ext_vector_type(2)));
-            v2f a0 = {pos.x, pos.y}, a1 = {pos.z, cameraX.x}, a2 = {cameraX.y, cameraX.z};
-            const v2f d0 = {delta.x, delta.y}, d1 = {delta.z, cameraDelta.x}, d2 = {cameraDelta.y, cameraDelta.z};
+            const f3 pos0 = xform(invTrack, p0);
+            const f3 cam0 = xform(K, pos0);
+            acc0 = v2f{pos0.x, pos0.y}; acc1 = v2f{pos0.z, cam0.x}; acc2 = v2f{cam0.y, cam0.z};
+        }
+        const v2f d0 = {delta.x, delta.y}, d1 = {delta.z, cameraDelta.x}, d2 = {cameraDelta.y, cameraDelta.z};
+        int zacc = 0;                    // the accumulators hold the state of step zacc
+        for (int r = 0; r < INTEGRATE_GROUP; ++r) {
+            if (!((group_mask >> r) & 1u)) continue;
+            const int bz = group * INTEGRATE_GROUP + r;
+            const int zc0 = max(a.z0, bz * a.zchunk);
+            const int zc1 = min(a.z1, (bz + 1) * a.zchunk);
 #pragma unroll 8
-            for (int z = 0; z < zc0; ++z) {
-                a0 += d0;
-                a1 += d1;
-                a2 += d2;
+            for (int z = zacc; z < zc0; ++z) {
+                acc0 += d0;
+                acc1 += d1;
+                acc2 += d2;
             }
-            pos = mk3(a0.x, a0.y, a1.x);
-            cameraX = mk3(a1.y, a2.x, a2.y);
-        }
-        // INTEGRATE_UNROLL z steps are advanced arithmetically, then their depth pixels and voxels are fetched
-        // together (the voxel read is issued as soon as the pixel test passes, before the depth value is
-        // known) and finally updated: one memory round trip per group instead of two per voxel.
-        for (int zb = zc0; zb < zc1; zb += INTEGRATE_UNROLL) {
-            f3 posk[INTEGRATE_UNROLL];
-            float camz[INTEGRATE_UNROLL];
-            unsigned pidx[INTEGRATE_UNROLL];
-            bool cand[INTEGRATE_UNROLL];
+            zacc = zc0;
+            f3 pos = mk3(acc0.x, acc0.y, acc1.x);
+            f3 cameraX = mk3(acc1.y, acc2.x, acc2.y);
+            // INTEGRATE_UNROLL z steps are advanced arithmetically, then their depth pixels and voxels are fetched
+            // together (the voxel read is issued as soon as the pixel test passes, before the depth value is
+            // known) and finally updated: one memory round trip per batch of steps instead of two per voxel.
+            for (int zb = zc0; zb < zc1; zb += INTEGRATE_UNROLL) {
+                f3 posk[INTEGRATE_UNROLL];
+                float camz[INTEGRATE_UNROLL];
+                unsigned pidx[INTEGRATE_UNROLL];
+                bool cand[INTEGRATE_UNROLL];
 #pragma unroll
-            for (int u = 0; u < INTEGRATE_UNROLL; ++u) {
-                const int z = zb + u;
-                posk[u] = pos;
-                camz[u] = cameraX.z;
-                bool c = in_vol && z < zc1 && !(pos.z < 0.0001f);
-                // Cheap conservative rejection (one pixel of slack, far above the rounding of the exact test):
-                // a voxel that fails it cannot pass the exact in-image test below.
-                if (c && (cameraX.x < -1.5f * cameraX.z || cameraX.x > (wmax + 1.5f) * cameraX.z ||
-                          cameraX.y < -1.5f * cameraX.z || cameraX.y > (hmax + 1.5f) * cameraX.z))
-                    c = false;
-                unsigned pi = 0;
-                if (c) {
-                    const float r1 = refined_rcp(cameraX.z);
-                    const float pxf = div_shared(cameraX.x, cameraX.z, r1) + 0.5f;
-                    const float pyf = div_shared(cameraX.y, cameraX.z, r1) + 0.5f;
-                    if (pxf < 0 || pxf > wmax || pyf < 0 || pyf > hmax) c = false;
-                    else pi = (unsigned)pxf + (unsigned)pyf * (unsigned)w;
-                }
-                cand[u] = c;
-                pidx[u] = pi;
-                pos = pos + delta;
-                cameraX = cameraX + cameraDelta;
-            }
-            float dk[INTEGRATE_UNROLL];
-            short2 rawk[INTEGRATE_UNROLL];
-#pragma unroll
-            for (int u = 0; u < INTEGRATE_UNROLL; ++u) {
-                dk[u] = 0.f;
-                rawk[u] = make_short2(0, 0);
-                if (cand[u]) {
-                    dk[u] = depth[pidx[u]];
-                    rawk[u] = col[(size_t)(zb + u - a.z0) * plane];
-                }
-                if (a.dbg) dbg_cand += __popcll(__ballot(cand[u]));
-            }
-#pragma unroll
-            for (int u = 0; u < INTEGRATE_UNROLL; ++u) {
-                if (!cand[u] || dk[u] == 0) continue;
-                // diff = (d - z) * s with s = sqrt(1 + rx^2 + ry^2) >= 1, so
-                //   d - z <= -mu  implies  diff <= -mu        (voxel behind the surface: untouched)
-                //   d - z >=  mu  implies  min(1, diff / mu) == 1   (free space)
-                // and only the band in between needs s.
-                const float dz = dk[u] - camz[u];
-                if (dz <= -mu) continue;
-                float sdf = 1.f;
-                if (dz < mu) {
-                    const float r1 = refined_rcp(posk[u].z);
-                    const float rx = div_shared(posk[u].x, posk[u].z, r1), ry = div_shared(posk[u].y, posk[u].z, r1);
-                    const float diff = dz * sqrtf(1 + rx * rx + ry * ry);
-                    if (!(diff > -mu)) continue;
-                    sdf = fminf(1.f, diff / mu);
-                }
-                {
-                    float tsdf = (float)rawk[u].x * KFH_SHORT2FLOAT;
-                    float wgt = (float)rawk[u].y;
-                    tsdf = fmaxf(-1.f, fminf((wgt * tsdf + sdf) / (wgt + 1), 1.f));
-                    wgt = fminf(wgt + 1, maxweight);
-                    const short2 out = make_short2((short)(tsdf * KFH_FLOAT2SHORT), (short)wgt);
-                    // free space seen often enough stays at (1, maxweight): nothing to store then
-                    if (out.x != rawk[u].x || out.y != rawk[u].y) {
-                        col[(size_t)(zb + u - a.z0) * plane] = out;
-                        if (a.dbg) ++dbg_written;
+                for (int u = 0; u < INTEGRATE_UNROLL; ++u) {
+                    const int z = zb + u;
+                    posk[u] = pos;
+                    camz[u] = cameraX.z;
+                    bool c = in_vol && z < zc1 && !(pos.z < 0.0001f);
+                    // Cheap conservative rejection (one pixel of slack, far above the rounding of the exact test):
+                    // a voxel that fails it cannot pass the exact in-image test below.
+                    if (c && (cameraX.x < -1.5f * cameraX.z || cameraX.x > (wmax + 1.5f) * cameraX.z ||
+                              cameraX.y < -1.5f * cameraX.z || cameraX.y > (hmax + 1.5f) * cameraX.z))
+                        c = false;
+                    unsigned pi = 0;
+                    if (c) {
+                        const float r1 = refined_rcp(cameraX.z);
+                        const float pxf = div_shared(cameraX.x, cameraX.z, r1) + 0.5f;
+                        const float pyf = div_shared(cameraX.y, cameraX.z, r1) + 0.5f;
+                        if (pxf < 0 || pxf > wmax || pyf < 0 || pyf > hmax) c = false;
+                        else pi = (unsigned)pxf + (unsigned)pyf * (unsigned)w;
                     }
-                    // The voxel drops below the level that lets a coarse raycast step pass unseen: every brick
-                    // whose samples can read it (its own, and the previous one along each axis where the voxel
-                    // is the first of its brick) loses its "nothing here" mark.  Marks are only ever cleared.
-                    if (a.bricks && rawk[u].x >= RAY_COARSE_SAFE && out.x < RAY_COARSE_SAFE) {
-                        const int z = zb + u;
-                        const int ex = ((x & 7) == 0 && x > 0) ? 1 : 0, ey = ((y & 7) == 0 && y > 0) ? 1 : 0;
-                        const int ez = ((z & 7) == 0 && z > 0) ? 1 : 0;
-                        for (int iz = 0; iz <= ez; ++iz)
-                            for (int iy = 0; iy <= ey; ++iy)
-                                for (int ix = 0; ix <= ex; ++ix)
-                                    a.bricks[((x >> 3) - ix) + a.bgx * (((y >> 3) - iy) + a.bgy * ((z >> 3) - iz))] = 0;
+                    cand[u] = c;
+                    pidx[u] = pi;
+                    pos = pos + delta;
+                    cameraX = cameraX + cameraDelta;
+                }
+                float dk[INTEGRATE_UNROLL];
+                short2 rawk[INTEGRATE_UNROLL];
+#pragma unroll
+                for (int u = 0; u < INTEGRATE_UNROLL; ++u) {
+                    dk[u] = 0.f;
+                    rawk[u] = make_short2(0, 0);
+                    if (cand[u]) {
+                        dk[u] = depth[pidx[u]];
+                        rawk[u] = col[(size_t)(zb + u - a.z0) * plane];
+                    }
+                    if (a.dbg) dbg_cand += __popcll(__ballot(cand[u]));
+                }
+#pragma unroll
+                for (int u = 0; u < INTEGRATE_UNROLL; ++u) {
+                    if (!cand[u] || dk[u] == 0) continue;
+                    // diff = (d - z) * s with s = sqrt(1 + rx^2 + ry^2) >= 1, so
+                    //   d - z <= -mu  implies  diff <= -mu        (voxel behind the surface: untouched)
+                    //   d - z >=  mu  implies  min(1, diff / mu) == 1   (free space)
+                    // and only the band in between needs s.
+                    const float dz = dk[u] - camz[u];
+                    if (dz <= -mu) continue;
+                    float sdf = 1.f;
+                    if (dz < mu) {
+                        const float r1 = refined_rcp(posk[u].z);
+                        const float rx = div_shared(posk[u].x, posk[u].z, r1), ry = div_shared(posk[u].y, posk[u].z, r1);
+                        const float diff = dz * sqrtf(1 + rx * rx + ry * ry);
+                        if (!(diff > -mu)) continue;
+                        sdf = fminf(1.f, diff / mu);
+                    }
+                    {
+                        float tsdf = (float)rawk[u].x * KFH_SHORT2FLOAT;
+                        float wgt = (float)rawk[u].y;
+                        tsdf = fmaxf(-1.f, fminf((wgt * tsdf + sdf) / (wgt + 1), 1.f));
+                        wgt = fminf(wgt + 1, maxweight);
+                        const short2 out = make_short2((short)(tsdf * KFH_FLOAT2SHORT), (short)wgt);
+                        // free space seen often enough stays at (1, maxweight): nothing to store then
+                        if (out.x != rawk[u].x || out.y != rawk[u].y) {
+                            col[(size_t)(zb + u - a.z0) * plane] = out;
+                            if (a.dbg) ++dbg_written;
+                        }
+                        // The voxel drops below the level that lets a coarse raycast step pass unseen: every brick
+                        // whose samples can read it (its own, and the previous one along each axis where the voxel
+                        // is the first of its brick) loses its "nothing here" mark.  Marks are only ever cleared.
+                        if (a.bricks && rawk[u].x >= RAY_COARSE_SAFE && out.x < RAY_COARSE_SAFE) {
+                            const int z = zb + u;
+                            const int ex = ((x & 7) == 0 && x > 0) ? 1 : 0, ey = ((y & 7) == 0 && y > 0) ? 1 : 0;
+                            const int ez = ((z & 7) == 0 && z > 0) ? 1 : 0;
+                            for (int iz = 0; iz <= ez; ++iz)
+                                for (int iy = 0; iy <= ey; ++iy)
+                                    for (int ix = 0; ix <= ex; ++ix)
+                                        a.bricks[((x >> 3) - ix) + a.bgx * (((y >> 3) - iy) + a.bgy * ((z >> 3) - iz))] = 0;
+                        }
                     }
                 }
             }
-        }
+            }   // boxes of the group
         if (a.dbg) {
             unsigned long long tot = dbg_written;
             for (int m = 32; m >= 1; m >>= 1) tot += __shfl_xor(tot, m, 64);
@@ -1801,6 +1828,14 @@ static int integrate_zchunk(int z1) {
     if (forced >= INTEGRATE_UNROLL && forced % INTEGRATE_UNROLL == 0) return forced;
     // measured per integration at 512^3: 16 -> 35 us, 32 -> 40 us, 64 -> 54 us; at 1024^3: 16 -> 126 us, 32 -> 104 us, 64 -> 107 us
     return z1 <= 512 ? 16 : z1 <= 1024 ? 32 : 64;
+}
+
+// Boxes per work item: the replay of a column's additions is paid once per item, but fewer and longer items
+// leave the device short of wavefronts while the volume is small.  KFH_INTEGRATE_GROUP overrides it for experiments.
+static int integrate_group(int z1) {
+    static const int forced = std::getenv("KFH_INTEGRATE_GROUP") ? std::atoi(std::getenv("KFH_INTEGRATE_GROUP")) : 0;
+    if (forced == 1 || forced == 2 || forced == 4) return forced;
+    return z1 <= 1024 ? 1 : 4;
 }
 
 size_t integrate_box_list_bytes(const int res[3], int z1) {
@@ -1827,10 +1862,21 @@ hipError_t launch_integrate(short2 *vol, const int res[3], const float dim[3], i
     a.bricks = bricks; a.bgx = (res[0] + 7) / 8; a.bgy = (res[1] + 7) / 8;
     a.tile_max = tile_max; a.tiles_x = (w + PRE_TX - 1) / PRE_TX; a.tiles_y = (h + PRE_TY - 1) / PRE_TY;
     a.dbg = g_integrate_debug;
-    if (a.gx > 256 || a.gy > 4096 || a.gz > 4096) return hipErrorInvalidValue;   // packed box id
-    const int nbox = a.gx * a.gy * a.gz;
-    hipLaunchKernelGGL(k_integrate_plan, dim3((nbox + 255) / 256), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(k_integrate, dim3(nbox < 2048 ? nbox : 2048), dim3(256), 0, s, a);
+    const int group = integrate_group(z1);
+    const int groups = (a.gz + group - 1) / group;
+    if (a.gx > 256 || a.gy > 4096 || groups > 256) return hipErrorInvalidValue;   // packed item
+    const int nitems = a.gx * a.gy * groups;          // plan: `group` threads per item
+    const dim3 plan_grid((nitems * group + 255) / 256), work_grid(nitems < 2048 ? nitems : 2048);
+    if (group == 4) {
+        hipLaunchKernelGGL(k_integrate_plan<4>, plan_grid, dim3(256), 0, s, a);
+        hipLaunchKernelGGL(k_integrate<4>, work_grid, dim3(256), 0, s, a);
+    } else if (group == 2) {
+        hipLaunchKernelGGL(k_integrate_plan<2>, plan_grid, dim3(256), 0, s, a);
+        hipLaunchKernelGGL(k_integrate<2>, work_grid, dim3(256), 0, s, a);
+    } else {
+        hipLaunchKernelGGL(k_integrate_plan<1>, plan_grid, dim3(256), 0, s, a);
+        hipLaunchKernelGGL(k_integrate<1>, work_grid, dim3(256), 0, s, a);
+    }
     return hipGetLastError();
 }
 
