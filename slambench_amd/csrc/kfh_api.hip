@@ -632,7 +632,9 @@ int kfh_end_frame(kfh_context *c) {
     KFH_REQUIRE(c != nullptr, "context is NULL");
     DeviceScope on_device(c->device);
     KFH_HIP(ensure_pre_done(c));
-    KFH_HIP(hipEventRecord(c->ev_set_free[c->cur_set], c->stream));   // this frame is done with its depth images
+    // this frame is done with its depth images: only the side stream of the overlap mode ever waits for that (an
+    // event record occupies the stream for a few microseconds, so it is not made for nothing)
+    if (c->overlap) KFH_HIP(hipEventRecord(c->ev_set_free[c->cur_set], c->stream));
     c->frame++;
     return KFH_OK;
 }
