@@ -84,6 +84,7 @@ struct kfh_context {
     int cur_set = 0;
     bool pre_pending = false;              // the main stream has not yet waited for ev_pre_done
     bool overlap = false;
+    bool tail_pending = false;             // the second pass of the last raycast has not been launched yet
     float4 *d_in_vertex[3] = {nullptr, nullptr, nullptr};
     float4 *d_in_normal[3] = {nullptr, nullptr, nullptr};
     float4 *d_vertex = nullptr, *d_normal = nullptr;
@@ -208,6 +209,7 @@ int init_state(kfh_context *c) {
     KFH_HIP(hipStreamSynchronize(c->pre_stream));
     KFH_HIP(hipStreamSynchronize(c->stream));
     c->pre_pending = false;
+    c->tail_pending = false;       // the maps it would complete are about to be cleared
     c->next_set = 0;
     select_set(c, 0);
     KFH_HIP(launch_fill_volume(c->d_volume, c->volume_voxels, c->stream));
@@ -377,6 +379,9 @@ int kfh_reset(kfh_context *c) {
     return init_state(c);
 }
 
+static int flush_tail(kfh_context *c);                                                    // below, with kfh_raycast
+static hipError_t raycast_part(kfh_context *c, int part, const PreprocessLaunch *pre);
+
 int kfh_upload_depth(kfh_context *c, const uint16_t *h_depth) {
     KFH_REQUIRE(c != nullptr && h_depth != nullptr, "NULL argument");
     DeviceScope on_device(c->device);
@@ -420,9 +425,20 @@ int kfh_preprocess(kfh_context *c) {
     if (side) KFH_HIP(hipStreamWaitEvent(ps, c->ev_set_free[set], 0));
     if (c->timing == 1) KFH_HIP(hipEventRecord(c->ev[c->frame % KFH_TIMING_RING][0], ps));
     // the depth pyramid of tracking (halfSampleRobustImageKernel twice) is produced by the same launch
-    KFH_HIP(launch_preprocess(c->d_float_depth, c->d_scaled[0], c->w, c->h, c->d_depth_cur, true,
-                              c->cfg.input_width, c->cfg.compute_size_ratio, c->cfg.depth_divisor, c->d_scaled[1],
-                              c->d_scaled[2], E_DELTA * 3, c->d_tile_max, ps));
+    if (c->tail_pending && !side) {
+        // together with the second pass of the previous frame's raycast
+        PreprocessLaunch pre;
+        pre.raw = c->d_float_depth; pre.filtered = c->d_scaled[0]; pre.ow = c->w; pre.oh = c->h; pre.in = c->d_depth_cur;
+        pre.iw = c->cfg.input_width; pre.ratio = c->cfg.compute_size_ratio; pre.divisor = c->cfg.depth_divisor;
+        pre.level1 = c->d_scaled[1]; pre.level2 = c->d_scaled[2]; pre.pyramid_e_d = E_DELTA * 3; pre.tile_max = c->d_tile_max;
+        c->tail_pending = false;
+        KFH_HIP(raycast_part(c, RAYCAST_TAIL, &pre));
+    } else {
+        if (int rc = flush_tail(c)) return rc;
+        KFH_HIP(launch_preprocess(c->d_float_depth, c->d_scaled[0], c->w, c->h, c->d_depth_cur, true,
+                                  c->cfg.input_width, c->cfg.compute_size_ratio, c->cfg.depth_divisor, c->d_scaled[1],
+                                  c->d_scaled[2], E_DELTA * 3, c->d_tile_max, ps));
+    }
     c->depth_version++;
     for (int i = 0; i < 2; ++i)      // a staging slot is free again once this launch has read it
         if (c->d_depth_cur == c->d_depth_in[i]) {
@@ -440,6 +456,7 @@ int kfh_preprocess(kfh_context *c) {
 int kfh_track(kfh_context *c) {
     KFH_REQUIRE(c != nullptr, "context is NULL");
     DeviceScope on_device(c->device);
+    if (int rc = flush_tail(c)) return rc;
     KFH_HIP(ensure_pre_done(c));
     int total_iterations = 0;
     for (int l = 0; l < 3; ++l) total_iterations += c->cfg.pyramid[l];
@@ -494,6 +511,7 @@ static const float *tile_max_for_integrate(const kfh_context *c) {
 int kfh_integrate(kfh_context *c) {
     KFH_REQUIRE(c != nullptr, "context is NULL");
     DeviceScope on_device(c->device);
+    if (int rc = flush_tail(c)) return rc;
     KFH_HIP(ensure_pre_done(c));
     if ((c->frame % c->cfg.integration_rate) == 0 || c->frame <= 3) {
         const float *src = c->cfg.integrate_filtered ? c->d_scaled[0] : c->d_float_depth;
@@ -518,14 +536,41 @@ static float raycast_step(const kfh_config &cfg) {
     return mind / (float)maxr;
 }
 
+// The frame's raycast, whole or in parts.  The second pass (the rays the march left unfinished) may be postponed:
+// nothing reads the model maps before the next frame's tracking, so it waits for the next frame's preprocessing
+// and shares that launch.  Every entry point that reads the maps, waits for the stream, hands out pointers or
+// changes what the pass reads (pose, volume, task list) launches a postponed pass first (flush_tail).
+static hipError_t raycast_part(kfh_context *c, int part, const PreprocessLaunch *pre) {
+    return launch_raycast_part(c->d_vertex, c->d_normal, c->d_ray_t, c->d_ref_tn, c->w, c->h, c->d_volume, c->cfg.vol_res,
+                               c->cfg.vol_dim, 0, c->cfg.vol_res[2], &c->d_ctrl->view, NEAR_PLANE, FAR_PLANE,
+                               raycast_step(c->cfg), 0.75f * c->cfg.mu, c->d_ray_tasks, &c->d_ctrl->ray_task_count,
+                               c->d_bricks, part, pre, c->stream);
+}
+
+static bool tail_may_wait(const kfh_context *c) {
+    static const bool off = std::getenv("KFH_NO_DEFERRED_TAIL") != nullptr;
+    return !off && !c->sharded && !c->overlap && c->timing != 1;
+}
+
+static int flush_tail(kfh_context *c) {
+    if (c->tail_pending) {
+        c->tail_pending = false;
+        KFH_HIP(raycast_part(c, RAYCAST_TAIL, nullptr));
+    }
+    return KFH_OK;
+}
+
 int kfh_raycast(kfh_context *c) {
     KFH_REQUIRE(c != nullptr, "context is NULL");
     DeviceScope on_device(c->device);
+    if (int rc = flush_tail(c)) return rc;
     if (c->frame > 2 && !c->sharded) {
-        KFH_HIP(launch_raycast(c->d_vertex, c->d_normal, c->d_ray_t, c->d_ref_tn, c->w, c->h, c->d_volume,
-                               c->cfg.vol_res, c->cfg.vol_dim, 0, c->cfg.vol_res[2], &c->d_ctrl->view, NEAR_PLANE, FAR_PLANE,
-                               raycast_step(c->cfg), 0.75f * c->cfg.mu, c->d_ray_tasks,
-                               &c->d_ctrl->ray_task_count, c->d_bricks, c->stream));
+        if (tail_may_wait(c)) {
+            KFH_HIP(raycast_part(c, RAYCAST_MARCH, nullptr));
+            c->tail_pending = true;
+        } else {
+            KFH_HIP(raycast_part(c, RAYCAST_BOTH, nullptr));
+        }
     }
     if (c->timing == 1) {
         KFH_HIP(hipEventRecord(c->ev[c->frame % KFH_TIMING_RING][4], c->stream));
@@ -537,6 +582,7 @@ int kfh_raycast(kfh_context *c) {
 int kfh_raycast_slab(kfh_context *c) {
     KFH_REQUIRE(c != nullptr, "context is NULL");
     DeviceScope on_device(c->device);
+    if (int rc = flush_tail(c)) return rc;
     if (c->frame > 2) {
         KFH_HIP(launch_raycast(c->d_vertex, c->d_normal, c->d_ray_t, nullptr, c->w, c->h, c->d_volume,
                                c->cfg.vol_res, c->cfg.vol_dim, c->cfg.slab_z0, c->cfg.slab_z1, &c->d_ctrl->view, NEAR_PLANE,
@@ -549,6 +595,7 @@ int kfh_raycast_slab(kfh_context *c) {
 int kfh_composite_slabs(kfh_context *c, const float *d_t, const void *d_vertex, const void *d_normal, int n_parts) {
     KFH_REQUIRE(c != nullptr && d_t && d_vertex && d_normal, "NULL argument");
     DeviceScope on_device(c->device);
+    if (int rc = flush_tail(c)) return rc;
     KFH_REQUIRE(n_parts >= 1 && n_parts <= 64, "n_parts=%d out of range", n_parts);
     if (c->frame > 2) {
         KFH_HIP(launch_composite(c->d_vertex, c->d_normal, c->d_ray_t, c->d_ref_tn, d_t, static_cast<const float4 *>(d_vertex),
@@ -575,6 +622,7 @@ int kfh_enable_track_render(kfh_context *c, int enabled) {
 int kfh_render_device(kfh_context *c, int image, const float view_pose[16], uint8_t *d_rgba) {
     KFH_REQUIRE(c != nullptr && d_rgba != nullptr, "NULL argument");
     DeviceScope on_device(c->device);
+    if (int rc = flush_tail(c)) return rc;
     const int npix = c->w * c->h;
     uchar4 *out = reinterpret_cast<uchar4 *>(d_rgba);
     KFH_HIP(ensure_pre_done(c));
@@ -652,6 +700,7 @@ int kfh_process_frame(kfh_context *c) {
 int kfh_sync(kfh_context *c) {
     KFH_REQUIRE(c != nullptr, "context is NULL");
     DeviceScope on_device(c->device);
+    if (int rc = flush_tail(c)) return rc;
     KFH_HIP(hipStreamSynchronize(c->pre_stream));
     KFH_HIP(hipStreamSynchronize(c->stream));
     return KFH_OK;
@@ -660,6 +709,7 @@ int kfh_sync(kfh_context *c) {
 int kfh_get_pose(kfh_context *c, float pose[16]) {
     KFH_REQUIRE(c != nullptr && pose != nullptr, "NULL argument");
     DeviceScope on_device(c->device);
+    if (int rc = flush_tail(c)) return rc;
     KFH_HIP(hipMemcpyAsync(pose, &c->d_ctrl->pose, sizeof(Mat4), hipMemcpyDeviceToHost, c->stream));
     KFH_HIP(hipStreamSynchronize(c->stream));
     return KFH_OK;
@@ -668,6 +718,7 @@ int kfh_get_pose(kfh_context *c, float pose[16]) {
 int kfh_set_pose(kfh_context *c, const float pose[16]) {
     KFH_REQUIRE(c != nullptr && pose != nullptr, "NULL argument");
     DeviceScope on_device(c->device);
+    if (int rc = flush_tail(c)) return rc;
     KFH_HIP(hipMemcpyAsync(&c->d_ctrl->pose, pose, sizeof(Mat4), hipMemcpyHostToDevice, c->stream));
     KFH_HIP(hipStreamSynchronize(c->stream));
     KFH_HIP(launch_pose_derive(c->d_ctrl, c->k, 0, c->stream));
@@ -677,6 +728,7 @@ int kfh_set_pose(kfh_context *c, const float pose[16]) {
 int kfh_get_status(kfh_context *c, int frame, kfh_frame_status *out) {
     KFH_REQUIRE(c != nullptr && out != nullptr, "NULL argument");
     DeviceScope on_device(c->device);
+    if (int rc = flush_tail(c)) return rc;
     KFH_REQUIRE(frame >= 0 && frame < c->frame && frame >= c->frame - KFH_STATUS_RING,
                 "frame %d is not in the retained window (%d frames processed)", frame, c->frame);
     KFH_HIP(hipMemcpyAsync(out, c->d_status + (frame % KFH_STATUS_RING), sizeof(kfh_frame_status),
@@ -701,6 +753,8 @@ int kfh_compute_size(kfh_context *c, int *w, int *h) {
 int kfh_device_ptr(kfh_context *c, int buffer, int level, void **d_ptr, size_t *bytes) {
     KFH_REQUIRE(c != nullptr && d_ptr != nullptr && bytes != nullptr, "NULL argument");
     KFH_REQUIRE(level >= 0 && level < 3, "level %d out of range", level);
+    DeviceScope on_device(c->device);
+    if (int rc = flush_tail(c)) return rc;     // the caller is about to read or copy the buffer
     const size_t npix = (size_t)c->w * c->h;
     const size_t nl = (size_t)(c->w >> level) * (c->h >> level);
     KFH_HIP(ensure_pre_done(c));     // the depth images may still be in the making on the other stream
@@ -748,6 +802,8 @@ int kfh_download(kfh_context *c, int buffer, int level, void *h_dst, size_t byte
 
 int kfh_stream(kfh_context *c, void **stream) {
     KFH_REQUIRE(c != nullptr && stream != nullptr, "NULL argument");
+    DeviceScope on_device(c->device);
+    if (int rc = flush_tail(c)) return rc;     // work the caller queues must find the frame complete
     *stream = c->stream;
     return KFH_OK;
 }
@@ -755,6 +811,7 @@ int kfh_stream(kfh_context *c, void **stream) {
 int kfh_set_timing(kfh_context *c, int mode) {
     KFH_REQUIRE(c != nullptr, "context is NULL");
     DeviceScope on_device(c->device);
+    if (int rc = flush_tail(c)) return rc;
     KFH_REQUIRE(mode >= 0 && mode <= 3, "timing mode must be 0, 1, 2 or 3");
     if (mode != 0 && !c->ev) {
         c->ev = new (std::nothrow) hipEvent_t[KFH_TIMING_RING][5]();
@@ -826,6 +883,7 @@ int kfh_debug_solver_us(const float *h_sums32, float *us_per_update) {
 int kfh_debug_integrate_stats(kfh_context *c, unsigned long long *h_out, size_t n_values) {
     KFH_REQUIRE(c != nullptr && h_out != nullptr, "NULL argument");
     DeviceScope on_device(c->device);
+    if (int rc = flush_tail(c)) return rc;
     if (!icp_stamps_compiled()) return fail(KFH_ERR_STATE, "this library was built without diagnostics (make -C slambench_amd/csrc clean && make -C slambench_amd/csrc STAMPS=1)");
     unsigned long long *d = nullptr;
     KFH_HIP(hipMalloc(reinterpret_cast<void **>(&d), n_values * sizeof(unsigned long long)));
@@ -854,6 +912,7 @@ int kfh_debug_integrate_stats(kfh_context *c, unsigned long long *h_out, size_t 
 int kfh_debug_raycast_stats(kfh_context *c, unsigned long long *h_out) {
     KFH_REQUIRE(c != nullptr && h_out != nullptr, "NULL argument");
     DeviceScope on_device(c->device);
+    if (int rc = flush_tail(c)) return rc;
     if (!icp_stamps_compiled()) return fail(KFH_ERR_STATE, "this library was built without diagnostics (make -C slambench_amd/csrc clean && make -C slambench_amd/csrc STAMPS=1)");
     const size_t n = (size_t)((c->w + 15) / 16) * ((c->h + 15) / 16) * 16;
     unsigned long long *d = nullptr;
@@ -881,6 +940,7 @@ int kfh_debug_raycast_stats(kfh_context *c, unsigned long long *h_out) {
 int kfh_debug_icp_stamps(kfh_context *c, unsigned long long *h_out) {
     KFH_REQUIRE(c != nullptr && h_out != nullptr, "NULL argument");
     DeviceScope on_device(c->device);
+    if (int rc = flush_tail(c)) return rc;
     if (!c->d_stamps) return fail(KFH_ERR_STATE, "context was created without KFH_ICP_STAMPS");
     if (!icp_stamps_compiled()) return fail(KFH_ERR_STATE, "this library was built without diagnostics (make -C slambench_amd/csrc clean && make -C slambench_amd/csrc STAMPS=1)");
     KFH_HIP(hipStreamSynchronize(c->stream));

@@ -173,6 +173,26 @@ hipError_t launch_raycast(float4 *vertex, float4 *normal, float *ray_t, float4 *
                           const short2 *vol, const int res[3], const float dim[3], int z0, int z1, const Mat4 *view,
                           float near_plane, float far_plane, float step, float largestep, void *tasks,
                           unsigned *task_count, const unsigned char *bricks, hipStream_t s);
+// The two launches separately, for a caller that postpones the second pass: nothing reads the maps between the
+// end of one frame and the tracking of the next, so the second pass may wait for the next frame's preprocessing
+// and share its launch (RAYCAST_TAIL with `with_preprocess`: what launch_preprocess would be given, u16 input
+// and both pyramid levels required).
+enum { RAYCAST_BOTH = 0, RAYCAST_MARCH = 1, RAYCAST_TAIL = 2 };
+struct PreprocessLaunch {
+    float *raw, *filtered;
+    int ow, oh;
+    const void *in;
+    int iw, ratio;
+    float divisor;
+    float *level1, *level2;
+    float pyramid_e_d;
+    float *tile_max;
+};
+hipError_t launch_raycast_part(float4 *vertex, float4 *normal, float *ray_t, float4 *ref_tn, int w, int h,
+                               const short2 *vol, const int res[3], const float dim[3], int z0, int z1,
+                               const Mat4 *view, float near_plane, float far_plane, float step, float largestep,
+                               void *tasks, unsigned *task_count, const unsigned char *bricks, int part,
+                               const PreprocessLaunch *with_preprocess, hipStream_t s);
 hipError_t launch_composite(float4 *vertex, float4 *normal, float *ray_t, float4 *ref_tn, const float *t_parts,
                             const float4 *v_parts, const float4 *n_parts, int n_parts_count, int npix,
                             hipStream_t s);

@@ -42,18 +42,19 @@ __device__ inline float half_sample_2x2(float tl, float tr, float bl, float br, 
 
 // With PYRAMID the block also half-samples its filtered 32x8 tile twice (16x4, then 8x2 pixels: the 2x2 blocks
 // of the robust half-sampling never straddle a tile), so the depth pyramid costs no further launches.
+// One block of 256 threads produces the tile (tile_x, tile_y) of a grid that is tiles_x tiles wide.
 template <bool IN_U16, bool PYRAMID>
-__global__ __launch_bounds__(256) void k_preprocess(float *__restrict__ raw, float *__restrict__ filtered,
-                                                    int ow, int oh, const void *__restrict__ in, int iw,
-                                                    int ratio, float divisor, BilateralConst bc,
-                                                    float *__restrict__ level1, float *__restrict__ level2,
-                                                    float pyramid_e_d, float *__restrict__ tile_max) {
+__device__ inline void preprocess_tile(float *__restrict__ raw, float *__restrict__ filtered, int ow, int oh,
+                                       const void *__restrict__ in, int iw, int ratio, float divisor,
+                                       const BilateralConst &bc, float *__restrict__ level1,
+                                       float *__restrict__ level2, float pyramid_e_d, float *__restrict__ tile_max,
+                                       int tile_x, int tile_y, int tiles_x) {
     __shared__ float tile[PRE_LH][PRE_LW];
     __shared__ float f0[PRE_TY][PRE_TX];
     __shared__ float f1[PRE_TY / 2][PRE_TX / 2];
     __shared__ float wave_max[4];
     const int tid = threadIdx.x;
-    const int bx = blockIdx.x * PRE_TX, by = blockIdx.y * PRE_TY;
+    const int bx = tile_x * PRE_TX, by = tile_y * PRE_TY;
     float vmax = 0.f;
     for (int idx = tid; idx < PRE_LW * PRE_LH; idx += 256) {
         const int ly = idx / PRE_LW, lx = idx - ly * PRE_LW;
@@ -77,7 +78,7 @@ __global__ __launch_bounds__(256) void k_preprocess(float *__restrict__ raw, flo
     }
     __syncthreads();
     if (tile_max && tid == 0)
-        tile_max[blockIdx.y * gridDim.x + blockIdx.x] = fmaxf(fmaxf(wave_max[0], wave_max[1]), fmaxf(wave_max[2], wave_max[3]));
+        tile_max[tile_y * tiles_x + tile_x] = fmaxf(fmaxf(wave_max[0], wave_max[1]), fmaxf(wave_max[2], wave_max[3]));
     const int tx = tid & (PRE_TX - 1), ty = tid >> 5;
     const int x = bx + tx, y = by + ty;
     const bool inside = x < ow && y < oh;
@@ -128,6 +129,16 @@ __global__ __launch_bounds__(256) void k_preprocess(float *__restrict__ raw, flo
         const int gx = bx / 4 + qx, gy = by / 4 + qy;
         if (gx < ow2 && gy < oh2) level2[gx + gy * ow2] = v;
     }
+}
+
+template <bool IN_U16, bool PYRAMID>
+__global__ __launch_bounds__(256) void k_preprocess(float *__restrict__ raw, float *__restrict__ filtered,
+                                                    int ow, int oh, const void *__restrict__ in, int iw,
+                                                    int ratio, float divisor, BilateralConst bc,
+                                                    float *__restrict__ level1, float *__restrict__ level2,
+                                                    float pyramid_e_d, float *__restrict__ tile_max) {
+    preprocess_tile<IN_U16, PYRAMID>(raw, filtered, ow, oh, in, iw, ratio, divisor, bc, level1, level2, pyramid_e_d,
+                                     tile_max, blockIdx.x, blockIdx.y, gridDim.x);
 }
 
 size_t depth_tile_count(int w, int h) { return (size_t)((w + PRE_TX - 1) / PRE_TX) * ((h + PRE_TY - 1) / PRE_TY); }
@@ -2324,22 +2335,21 @@ __global__ __launch_bounds__(256, 5) void k_raycast_march(float4 *__restrict__ v
 // rays (grazing a surface with the fine step) thus take a sixteenth of the dependent round trips, and
 // the task list spreads them over the whole device instead of the few tiles they come from.
 template <bool POW2, int OFFW, int RAY_TAIL_LANES>
-__global__ __launch_bounds__(256) void k_raycast_tail(float4 *__restrict__ vertex, float4 *__restrict__ normal,
-                                                      float *__restrict__ ray_t, float4 *__restrict__ ref_tn, int w,
-                                                      int h, VolDev<POW2, OFFW> vol, float zc0, float zc1,
-                                                      const Mat4 *__restrict__ view_p, float near_plane,
-                                                      float far_plane, float step, float largestep,
-                                                      const RayTask *__restrict__ tasks,
-                                                      const unsigned *__restrict__ task_count) {
+__device__ inline void raycast_tail_block(float4 *__restrict__ vertex, float4 *__restrict__ normal,
+                                          float *__restrict__ ray_t, float4 *__restrict__ ref_tn, int w, int h,
+                                          const VolDev<POW2, OFFW> &vol, float zc0, float zc1,
+                                          const Mat4 *__restrict__ view_p, float near_plane, float far_plane,
+                                          float step, float largestep, const RayTask *__restrict__ tasks,
+                                          const unsigned *__restrict__ task_count, unsigned block, unsigned blocks) {
     constexpr int GROUPS = 64 / RAY_TAIL_LANES;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int grp = lane / RAY_TAIL_LANES, sub = lane % RAY_TAIL_LANES;
     const int grp_lane0 = grp * RAY_TAIL_LANES;
     const unsigned n = *task_count;
-    const unsigned stride = gridDim.x * 4 * GROUPS;
+    const unsigned stride = blocks * 4 * GROUPS;
     const Mat4 view = *view_p;
     const f3 origin = mk3(view.m[3], view.m[7], view.m[11]);
-    for (unsigned base = (blockIdx.x * 4 + wave) * GROUPS; base < n; base += stride) {      // wave-uniform
+    for (unsigned base = (block * 4 + wave) * GROUPS; base < n; base += stride) {      // wave-uniform
         const unsigned gi = base + grp;
         const bool have = gi < n;
         RayTask e;
@@ -2399,6 +2409,54 @@ __global__ __launch_bounds__(256) void k_raycast_tail(float4 *__restrict__ verte
     }
 }
 
+template <bool POW2, int OFFW, int RAY_TAIL_LANES>
+__global__ __launch_bounds__(256) void k_raycast_tail(float4 *__restrict__ vertex, float4 *__restrict__ normal,
+                                                      float *__restrict__ ray_t, float4 *__restrict__ ref_tn, int w,
+                                                      int h, VolDev<POW2, OFFW> vol, float zc0, float zc1,
+                                                      const Mat4 *__restrict__ view_p, float near_plane,
+                                                      float far_plane, float step, float largestep,
+                                                      const RayTask *__restrict__ tasks,
+                                                      const unsigned *__restrict__ task_count) {
+    raycast_tail_block<POW2, OFFW, RAY_TAIL_LANES>(vertex, normal, ray_t, ref_tn, w, h, vol, zc0, zc1, view_p, near_plane,
+                                                   far_plane, step, largestep, tasks, task_count, blockIdx.x, gridDim.x);
+}
+
+// The second pass of one frame's raycast and the preprocessing of the next frame in one launch: neither depends
+// on the other, each leaves most of the device idle on its own, and a launch boundary is saved.  The blocks of
+// the second pass come first (its longest rays decide when the launch ends).
+struct PreprocessArgs {
+    float *raw, *filtered;
+    int ow, oh;
+    const void *in;
+    int iw, ratio;
+    float divisor;
+    BilateralConst bc;
+    float *level1, *level2;
+    float pyramid_e_d;
+    float *tile_max;
+    int tiles_x, tiles_y;
+};
+
+template <bool POW2, int OFFW>
+__global__ __launch_bounds__(256) void k_raycast_tail_preprocess(float4 *__restrict__ vertex, float4 *__restrict__ normal,
+                                                                 float *__restrict__ ray_t, float4 *__restrict__ ref_tn,
+                                                                 int w, int h, VolDev<POW2, OFFW> vol, float zc0,
+                                                                 float zc1, const Mat4 *__restrict__ view_p,
+                                                                 float near_plane, float far_plane, float step,
+                                                                 float largestep, const RayTask *__restrict__ tasks,
+                                                                 const unsigned *__restrict__ task_count,
+                                                                 unsigned tail_blocks, PreprocessArgs pre) {
+    if (blockIdx.x < tail_blocks) {
+        raycast_tail_block<POW2, OFFW, 32>(vertex, normal, ray_t, ref_tn, w, h, vol, zc0, zc1, view_p, near_plane,
+                                           far_plane, step, largestep, tasks, task_count, blockIdx.x, tail_blocks);
+    } else {
+        const int t = (int)(blockIdx.x - tail_blocks);
+        preprocess_tile<true, true>(pre.raw, pre.filtered, pre.ow, pre.oh, pre.in, pre.iw, pre.ratio, pre.divisor, pre.bc,
+                                    pre.level1, pre.level2, pre.pyramid_e_d, pre.tile_max, t % pre.tiles_x,
+                                    t / pre.tiles_x, pre.tiles_x);
+    }
+}
+
 static unsigned long long *g_raycast_debug = nullptr;   // diagnostics buffer, [blocks][4 waves][4]
 void set_raycast_debug(unsigned long long *d_buffer) { g_raycast_debug = d_buffer; }
 
@@ -2406,7 +2464,8 @@ template <bool POW2, int OFFW>
 static hipError_t launch_raycast_t(float4 *vertex, float4 *normal, float *ray_t, float4 *ref_tn, int w, int h,
                                    const short2 *vol, const int res[3], const float dim[3], int z0, int z1,
                                    const Mat4 *view, float near_plane, float far_plane, float step, float largestep,
-                                   void *tasks, unsigned *task_count, const unsigned char *bricks, hipStream_t s) {
+                                   void *tasks, unsigned *task_count, const unsigned char *bricks, int part,
+                                   const PreprocessLaunch *pre, hipStream_t s) {
     VolDev<POW2, OFFW> v;
     v.data = vol;
     v.bricks = bricks;
@@ -2437,10 +2496,25 @@ static hipError_t launch_raycast_t(float4 *vertex, float4 *normal, float *ray_t,
     static const int max_rounds = std::getenv("KFH_RAY_ROUNDS") ? std::atoi(std::getenv("KFH_RAY_ROUNDS")) : RAY_MAX_ROUNDS;
     static const int few = std::getenv("KFH_RAY_FEW") ? std::atoi(std::getenv("KFH_RAY_FEW")) : RAY_FEW;
     static const int tail_lanes = std::getenv("KFH_RAY_TAIL_LANES") ? std::atoi(std::getenv("KFH_RAY_TAIL_LANES")) : 32;
-    hipLaunchKernelGGL((k_raycast_march<POW2, OFFW>), grid, dim3(256), 0, s, vertex, normal, ray_t, ref_tn, w, h, v, zc0, zc1,
-                       view, near_plane, far_plane, step, largestep, static_cast<RayTask *>(tasks), task_count,
-                       max_rounds, few, g_raycast_debug);
+    if (part != RAYCAST_TAIL)
+        hipLaunchKernelGGL((k_raycast_march<POW2, OFFW>), grid, dim3(256), 0, s, vertex, normal, ray_t, ref_tn, w, h, v, zc0, zc1,
+                           view, near_plane, far_plane, step, largestep, static_cast<RayTask *>(tasks), task_count,
+                           max_rounds, few, g_raycast_debug);
+    if (part == RAYCAST_MARCH) return hipGetLastError();
     const RayTask *ct = static_cast<const RayTask *>(tasks);
+    if (pre != nullptr && tail_lanes == 32) {
+        // the second pass together with the preprocessing of the next frame
+        PreprocessArgs pa;
+        pa.raw = pre->raw; pa.filtered = pre->filtered; pa.ow = pre->ow; pa.oh = pre->oh; pa.in = pre->in;
+        pa.iw = pre->iw; pa.ratio = pre->ratio; pa.divisor = pre->divisor; pa.bc = bilateral_const();
+        pa.level1 = pre->level1; pa.level2 = pre->level2; pa.pyramid_e_d = pre->pyramid_e_d; pa.tile_max = pre->tile_max;
+        pa.tiles_x = (pre->ow + PRE_TX - 1) / PRE_TX; pa.tiles_y = (pre->oh + PRE_TY - 1) / PRE_TY;
+        const unsigned tail_blocks = RAY_TAIL_BLOCKS;
+        hipLaunchKernelGGL((k_raycast_tail_preprocess<POW2, OFFW>), dim3(tail_blocks + pa.tiles_x * pa.tiles_y), dim3(256), 0,
+                           s, vertex, normal, ray_t, ref_tn, w, h, v, zc0, zc1, view, near_plane, far_plane, step, largestep,
+                           ct, task_count, tail_blocks, pa);
+        return hipGetLastError();
+    }
     if (tail_lanes == 64)
         hipLaunchKernelGGL((k_raycast_tail<POW2, OFFW, 64>), dim3(RAY_TAIL_BLOCKS * 2), dim3(256), 0, s, vertex, normal, ray_t,
                            ref_tn, w, h, v, zc0, zc1, view, near_plane, far_plane, step, largestep, ct, task_count);
@@ -2450,6 +2524,9 @@ static hipError_t launch_raycast_t(float4 *vertex, float4 *normal, float *ray_t,
     else
         hipLaunchKernelGGL((k_raycast_tail<POW2, OFFW, 16>), dim3(RAY_TAIL_BLOCKS), dim3(256), 0, s, vertex, normal, ray_t,
                            ref_tn, w, h, v, zc0, zc1, view, near_plane, far_plane, step, largestep, ct, task_count);
+    if (pre != nullptr)      // no fused variant for this lane count: the preprocessing follows on its own
+        return launch_preprocess(pre->raw, pre->filtered, pre->ow, pre->oh, pre->in, true, pre->iw, pre->ratio, pre->divisor,
+                                 pre->level1, pre->level2, pre->pyramid_e_d, pre->tile_max, s);
     return hipGetLastError();
 }
 
@@ -2459,7 +2536,19 @@ hipError_t launch_raycast(float4 *vertex, float4 *normal, float *ray_t, float4 *
                           const short2 *vol, const int res[3], const float dim[3], int z0, int z1, const Mat4 *view,
                           float near_plane, float far_plane, float step, float largestep, void *tasks,
                           unsigned *task_count, const unsigned char *bricks, hipStream_t s) {
+    return launch_raycast_part(vertex, normal, ray_t, ref_tn, w, h, vol, res, dim, z0, z1, view, near_plane, far_plane,
+                               step, largestep, tasks, task_count, bricks, RAYCAST_BOTH, nullptr, s);
+}
+
+hipError_t launch_raycast_part(float4 *vertex, float4 *normal, float *ray_t, float4 *ref_tn, int w, int h,
+                               const short2 *vol, const int res[3], const float dim[3], int z0, int z1,
+                               const Mat4 *view, float near_plane, float far_plane, float step, float largestep,
+                               void *tasks, unsigned *task_count, const unsigned char *bricks, int part,
+                               const PreprocessLaunch *pre, hipStream_t s) {
     if (bricks && !(z0 == 0 && z1 == res[2])) return hipErrorInvalidValue;   // marks describe whole volumes only
+    if (pre != nullptr && (part != RAYCAST_TAIL || !pre->filtered || !pre->level1 || !pre->level2 || pre->ow % 4 != 0 ||
+                           pre->oh % 4 != 0))
+        return hipErrorInvalidValue;
     bool pow2 = true;
     for (int i = 0; i < 3; ++i) {
         int e = 0;
@@ -2472,7 +2561,7 @@ hipError_t launch_raycast(float4 *vertex, float4 *normal, float *ray_t, float4 *
     if ((double)res[0] * res[1] > 2147483647.0) return hipErrorInvalidValue;      // a plane is indexed with 32 bits
     const int offw = stored_voxels * sizeof(short2) <= 4294967296.0 - 16.0 ? 0 : stored_voxels <= 4294967296.0 - 4.0 ? 1 : 2;
 #define KFH_RAYCAST_ARGS vertex, normal, ray_t, ref_tn, w, h, vol, res, dim, z0, z1, view, near_plane, far_plane, step, \
-                         largestep, tasks, task_count, bricks, s
+                         largestep, tasks, task_count, bricks, part, pre, s
     if (pow2)
         return offw == 0 ? launch_raycast_t<true, 0>(KFH_RAYCAST_ARGS)
              : offw == 1 ? launch_raycast_t<true, 1>(KFH_RAYCAST_ARGS) : launch_raycast_t<true, 2>(KFH_RAYCAST_ARGS);

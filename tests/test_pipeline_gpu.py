@@ -282,7 +282,8 @@ def test_tuning_switches_do_not_change_results(torch_cuda):
     variants = [{}, {"KFH_NO_BRICK_MARKS": "1"}, {"KFH_NO_DEPTH_CULL": "1"}, {"KFH_INTEGRATE_ZCHUNK": "64"},
                 {"KFH_INTEGRATE_ZCHUNK": "8", "KFH_RAY_ROUNDS": "3", "KFH_RAY_FEW": "32"},
                 {"KFH_RAY_TAIL_LANES": "16", "KFH_UPLOAD_COPY_ENGINE": "1"}, {"KFH_OVERLAP_PREPROCESS": "1"},
-                {"KFH_INTEGRATE_GROUP": "4"}, {"KFH_INTEGRATE_GROUP": "2", "KFH_INTEGRATE_ZCHUNK": "8"}]
+                {"KFH_INTEGRATE_GROUP": "4"}, {"KFH_INTEGRATE_GROUP": "2", "KFH_INTEGRATE_ZCHUNK": "8"},
+                {"KFH_NO_DEFERRED_TAIL": "1"}]
     hashes = []
     for extra in variants:
         env = dict(os.environ)
