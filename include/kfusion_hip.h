@@ -27,7 +27,13 @@
  *   - a context belongs to the device that was current in kfh_create; every kfh_* call on it makes
  *     that device current for its own duration and restores the caller's, so contexts of several
  *     devices can be driven from one thread or from one thread each.  Calls on ONE context must not
- *     overlap; calls on different contexts may (kfh_last_error() is per thread).
+ *     overlap; calls on different contexts may (kfh_last_error() is per thread);
+ *   - everything is queued on the context's stream and nothing waits unless said so.  The second
+ *     pass of a frame's raycast may stay unqueued until the next frame's preprocessing (it then
+ *     shares that launch) or until a call that reads the model maps, waits for the stream, returns
+ *     a device pointer or the stream, or changes pose or volume: all of these queue it first, so
+ *     results never depend on it.  Work queued on the stream from kfh_stream() by the caller
+ *     after further kfh_* calls must ask for the stream again.
  */
 #ifndef KFUSION_HIP_H_
 #define KFUSION_HIP_H_
