@@ -709,7 +709,7 @@ int kfh_sync(kfh_context *c) {
 int kfh_get_pose(kfh_context *c, float pose[16]) {
     KFH_REQUIRE(c != nullptr && pose != nullptr, "NULL argument");
     DeviceScope on_device(c->device);
-    if (int rc = flush_tail(c)) return rc;
+    // the pose and the status record are final once tracking has finished: a postponed raycast pass may stay postponed
     KFH_HIP(hipMemcpyAsync(pose, &c->d_ctrl->pose, sizeof(Mat4), hipMemcpyDeviceToHost, c->stream));
     KFH_HIP(hipStreamSynchronize(c->stream));
     return KFH_OK;
@@ -728,7 +728,7 @@ int kfh_set_pose(kfh_context *c, const float pose[16]) {
 int kfh_get_status(kfh_context *c, int frame, kfh_frame_status *out) {
     KFH_REQUIRE(c != nullptr && out != nullptr, "NULL argument");
     DeviceScope on_device(c->device);
-    if (int rc = flush_tail(c)) return rc;
+    // the pose and the status record are final once tracking has finished: a postponed raycast pass may stay postponed
     KFH_REQUIRE(frame >= 0 && frame < c->frame && frame >= c->frame - KFH_STATUS_RING,
                 "frame %d is not in the retained window (%d frames processed)", frame, c->frame);
     KFH_HIP(hipMemcpyAsync(out, c->d_status + (frame % KFH_STATUS_RING), sizeof(kfh_frame_status),
