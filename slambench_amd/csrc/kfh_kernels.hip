@@ -1988,8 +1988,12 @@ struct VolDev {
         const int bx = (int)flx, by = (int)fly, bz = (int)flz;
         Tap t;
         t.f = mk3(sp.x - flx, sp.y - fly, sp.z - flz);
-        const int lx = max(bx, 0), ly = max(by, 0), lz = max(bz, 0);
-        const int ux = min(bx + 1, sx - 1), uy = min(by + 1, sy - 1), uz = min(bz + 1, sz - 1);
+        // Inside the volume these are the reference's max(base, 0) / min(base + 1, size - 1).  The march also
+        // fetches (and discards) a sample up to one coarse step past the far end of its ray, which can lie more
+        // than a voxel outside the volume: rows are clamped on both sides so that such a fetch stays inside the
+        // allocation (x0 and plane() already are).
+        const int lx = max(bx, 0), ly = min(max(by, 0), sy - 1), lz = max(bz, 0);
+        const int ux = min(bx + 1, sx - 1), uy = max(min(by + 1, sy - 1), 0), uz = min(bz + 1, sz - 1);
         const int x0 = min(lx, sx - 2);
         t.l_second = lx != x0;
         t.u_second = ux != x0;
@@ -2051,10 +2055,12 @@ struct VolDev {
         const float flx = floorf(sp.x), fly = floorf(sp.y), flz = floorf(sp.z);
         const int bx = (int)flx, by = (int)fly, bz = (int)flz;
         const f3 f = mk3(sp.x - flx, sp.y - fly, sp.z - flz);
-        const int llx = max(bx - 1, 0), lly = max(by - 1, 0), llz = max(bz - 1, 0);
-        const int lux = max(bx, 0), luy = max(by, 0), luz = max(bz, 0);
-        const int ulx = min(bx + 1, sx - 1), uly = min(by + 1, sy - 1), ulz = min(bz + 1, sz - 1);
-        const int uux = min(bx + 2, sx - 1), uuy = min(by + 2, sy - 1), uuz = min(bz + 2, sz - 1);
+        // the reference's clamps (one side each); the other side only acts on positions outside the volume, which
+        // a hit never is, and keeps every fetch inside the allocation whatever the caller passes
+        const int llx = min(max(bx - 1, 0), sx - 1), lly = min(max(by - 1, 0), sy - 1), llz = max(bz - 1, 0);
+        const int lux = min(max(bx, 0), sx - 1), luy = min(max(by, 0), sy - 1), luz = max(bz, 0);
+        const int ulx = max(min(bx + 1, sx - 1), 0), uly = max(min(by + 1, sy - 1), 0), ulz = min(bz + 1, sz - 1);
+        const int uux = max(min(bx + 2, sx - 1), 0), uuy = max(min(by + 2, sy - 1), 0), uuz = min(bz + 2, sz - 1);
         const int lx = lux, ly = luy, lz = luz;
         const int ux = ulx, uy = uly, uz = ulz;
         f3 g;

@@ -48,7 +48,13 @@ def _draw(seed):
     return kw, pose, int(rng.integers(1, 50)), size, intr
 
 
-@pytest.mark.parametrize("seed", range(int(os.environ.get("KFH_FUZZ_SEEDS", "16"))))
+# beyond the sweep: 234 (a stream on which one nudge direction shows no sensitivity and the others millimetres) and
+# 997 (rays that leave the volume through the edge y = 0, z = 0 one coarse step past their far end)
+_SEEDS = list(range(int(os.environ.get("KFH_FUZZ_SEEDS", "16"))))
+_SEEDS += [s for s in (234, 997) if s not in _SEEDS]
+
+
+@pytest.mark.parametrize("seed", _SEEDS)
 def test_random_configuration(torch_cuda, seed):
     kw, pose, stream_seed, size, intr = _draw(seed)
     cfg = KFusionConfig(**kw)
