@@ -50,7 +50,8 @@ def _draw(seed):
 
 # beyond the sweep: 234 (a stream on which one nudge direction shows no sensitivity and the others millimetres) and
 # 997 (rays that leave the volume through the edge y = 0, z = 0 one coarse step past their far end)
-_SEEDS = list(range(int(os.environ.get("KFH_FUZZ_SEEDS", "16"))))
+_FIRST = int(os.environ.get("KFH_FUZZ_FIRST", "0"))
+_SEEDS = list(range(_FIRST, _FIRST + int(os.environ.get("KFH_FUZZ_SEEDS", "16"))))
 _SEEDS += [s for s in (234, 997) if s not in _SEEDS]
 
 
