@@ -419,12 +419,17 @@ void kfr_track(kfr_track_data *out, int out_stride, const float *in_vertex3, con
 /* kernels.cpp new_reduce + reduceKernel: 8 row-strided partials of 32 floats, then rows 1..7
  * added onto row 0.  Layout of a row: [0] sum e^2, [1..6] sum e*J, [7..27] upper triangle of
  * sum J J^T (row-major), [28] valid, [29] result==-4, [30] result==-5, [31] result>-4 (and <1). */
+static int g_reduce_rows = 8;       /* 8 is the reference's layout; tests pick another summation order with fewer */
+void kfr_set_reduce_rows(int rows) { g_reduce_rows = rows < 1 ? 1 : rows > 8 ? 8 : rows; }
+
 void kfr_reduce(float out[8 * 32], const kfr_track_data *J, int j_stride, int w, int h) {
+    const int rows = g_reduce_rows;
+    for (int i = 0; i < 8 * 32; ++i) out[i] = 0.0f;
 #pragma omp parallel for
-    for (int b = 0; b < 8; ++b) {
+    for (int b = 0; b < rows; ++b) {
         float s[32];
         for (int i = 0; i < 32; ++i) s[i] = 0.0f;
-        for (int y = b; y < h; y += 8)
+        for (int y = b; y < h; y += rows)
             for (int x = 0; x < w; ++x) {
                 const kfr_track_data &row = J[x + y * j_stride];
                 if (row.result < 1) {
@@ -448,6 +453,9 @@ void kfr_reduce(float out[8 * 32], const kfr_track_data *J, int j_stride, int w,
 
 /* kernels.cpp solve(): b = vals[0..5], C from the upper triangle vals[6..26];
  * TooN GR_SVD<6,6>::backsub(b, 1e6) in double. */
+static thread_local double g_cutoff_margin = 1e300;   /* of the last kfr_solve on this thread */
+double kfr_last_cutoff_margin(void) { return g_cutoff_margin; }
+
 void kfr_solve(double x[6], const float vals[27]) {
     double b[6], C[6][6], V[6][6], w[6];
     for (int i = 0; i < 6; ++i) b[i] = vals[i];
@@ -458,6 +466,10 @@ void kfr_solve(double x[6], const float vals[27]) {
     double wmax = 0.0;
     for (int i = 0; i < 6; ++i) wmax = fmax(wmax, fabs(w[i]));
     for (int i = 0; i < 6; ++i) x[i] = 0.0;
+    /* diagnostic: how close the nearest keep/drop decision came to its limit, |ln(|w_i| * 1e6 / wmax)| */
+    g_cutoff_margin = 1e300;
+    for (int i = 0; i < 6; ++i)
+        if (fabs(w[i]) > 0.0 && wmax > 0.0) g_cutoff_margin = fmin(g_cutoff_margin, fabs(log(fabs(w[i]) * 1e6 / wmax)));
     for (int i = 0; i < 6; ++i) {
         if (!(fabs(w[i]) * 1e6 > wmax)) continue;
         double p = 0.0;
@@ -715,6 +727,7 @@ struct kfr_context {
     float reduction[8 * 32];
     int tracked;
     int icp_iterations;      /* track + reduce passes of the last frame (all levels) */
+    double cutoff_margin;    /* smallest kfr_last_cutoff_margin() of those passes */
 };
 
 kfr_context *kfr_create(const kfr_config *cfg) {
@@ -727,6 +740,8 @@ kfr_context *kfr_create(const kfr_config *cfg) {
     c->k[2] = cfg->cx / (float)r; c->k[3] = cfg->cy / (float)r;
     c->frame = 0;
     c->tracked = 0;
+    c->icp_iterations = 0;
+    c->cutoff_margin = 1e300;
     M4 p;
     p.r[0] = f4{1, 0, 0, cfg->init_pos[0]};
     p.r[1] = f4{0, 1, 0, cfg->init_pos[1]};
@@ -784,6 +799,7 @@ int kfr_process_frame(kfr_context *c, const uint16_t *depth, double *phase_secon
         }
         c->old_pose = c->pose;
         c->icp_iterations = 0;
+        c->cutoff_margin = 1e300;
         const M4 project_reference =
             mat_mul(camera_matrix(c->k[0], c->k[1], c->k[2], c->k[3]), mat_inverse(c->raycast_pose));
         for (int level = 2; level >= 0; --level) {
@@ -794,7 +810,9 @@ int kfr_process_frame(kfr_context *c, const uint16_t *depth, double *phase_secon
                           &c->pose.r[0].x, &project_reference.r[0].x, 0.1f, 0.8f);
                 kfr_reduce(c->reduction, c->tracking_result.data(), w, lw, lh);
                 c->icp_iterations++;
-                if (kfr_update_pose(&c->pose.r[0].x, c->reduction, cfg.icp_threshold)) break;
+                const int converged = kfr_update_pose(&c->pose.r[0].x, c->reduction, cfg.icp_threshold);
+                c->cutoff_margin = fmin(c->cutoff_margin, kfr_last_cutoff_margin());
+                if (converged) break;
             }
         }
         tracked = kfr_check_pose(&c->pose.r[0].x, &c->old_pose.r[0].x, c->reduction, w, h, 0.15f);
@@ -859,6 +877,7 @@ const float *kfr_model_normal(const kfr_context *c) { return c->normal.data(); }
 const int16_t *kfr_volume(const kfr_context *c) { return c->volume.data(); }
 const float *kfr_reduction(const kfr_context *c) { return c->reduction; }
 int kfr_icp_iterations(const kfr_context *c) { return c->icp_iterations; }
+double kfr_cutoff_margin(const kfr_context *c) { return c->cutoff_margin; }
 const kfr_track_data *kfr_tracking_result(const kfr_context *c) { return c->tracking_result.data(); }
 
 }  /* extern "C" */

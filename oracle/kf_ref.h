@@ -105,6 +105,9 @@ const float   *kfr_model_normal(const kfr_context *c);
 const int16_t *kfr_volume(const kfr_context *c);
 const float   *kfr_reduction(const kfr_context *c);
 int kfr_icp_iterations(const kfr_context *c);                       /* track + reduce passes of the last tracked-rate frame */
+double kfr_cutoff_margin(const kfr_context *c);                    /* smallest |ln(|w_i| * 1e6 / max|w|)| over the solves of that frame: how close a keep/drop decision of the singular-value cut-off came to its limit */
+double kfr_last_cutoff_margin(void);                               /* the same for the last kfr_solve of the calling thread */
+void kfr_set_reduce_rows(int rows);                                /* test aid: kfr_reduce sums over `rows` strided partial rows (1..8) instead of the reference's 8: the same sums in another order */
 const kfr_track_data *kfr_tracking_result(const kfr_context *c);   /* [h][w] of the compute size, last iteration run */
 
 #ifdef __cplusplus

@@ -73,12 +73,20 @@ def lib():
             getattr(L, name).argtypes = [C.c_void_p, C.c_int]
         L.kfr_icp_iterations.restype = C.c_int
         L.kfr_icp_iterations.argtypes = [C.c_void_p]
+        L.kfr_cutoff_margin.restype = C.c_double
+        L.kfr_cutoff_margin.argtypes = [C.c_void_p]
         L.kfr_set_threads.restype = C.c_int
         L.kfr_set_threads.argtypes = [C.c_int]
         L.kfr_update_pose.restype = C.c_int
         L.kfr_check_pose.restype = C.c_int
         _lib = L
     return _lib
+
+
+def set_reduce_rows(rows=8):
+    """Test aid: the ICP sums over `rows` strided partial rows instead of the reference's 8 (another summation
+    order of the same terms).  Process-wide; restore 8 afterwards."""
+    lib().kfr_set_reduce_rows(C.c_int(rows))
 
 
 def set_threads(n=0):
@@ -347,6 +355,11 @@ class KFusionRef:
     def icp_iterations(self):
         """Track + reduce passes of the last frame on which tracking ran."""
         return lib().kfr_icp_iterations(self._c)
+
+    def cutoff_margin(self):
+        """Smallest |ln(|w_i| * 1e6 / max|w|)| over the solves of the last tracked frame: below a few percent a
+        keep/drop decision of the singular-value cut-off sat on its limit (float32 sums decide it by rounding)."""
+        return float(lib().kfr_cutoff_margin(self._c))
 
     def tracking_result(self):
         return self._view(lib().kfr_tracking_result(self._c), (self.h, self.w), TRACK_DTYPE)

@@ -45,14 +45,22 @@ def _draw(seed):
     pose = np.eye(4, dtype=np.float32)
     pose[:3, :3] = _random_rotation(rng, 180 if rng.random() < 0.5 else 20).astype(np.float32)
     pose[:3, 3] = np.asarray(kw["volume_direction"], np.float32) + rng.uniform(-0.2, 0.2, 3).astype(np.float32)
-    return kw, pose, int(rng.integers(1, 50)), size, intr
+    stream_seed = int(rng.integers(1, 50))
+    if seed >= 2000:
+        # seeds from 2000 on: the camera starts anywhere in the volume, up to its faces (rays leave the volume at
+        # once, much of the scene lies outside it); drawn last so that the earlier seeds keep their meaning
+        pose[:3, 3] += (rng.uniform(-0.45, 0.45, 3) * np.asarray(vol)).astype(np.float32)
+    return kw, pose, stream_seed, size, intr
 
 
 # beyond the sweep: 234 (a stream on which one nudge direction shows no sensitivity and the others millimetres) and
-# 997 (rays that leave the volume through the edge y = 0, z = 0 one coarse step past their far end)
+# 997 (rays that leave the volume through the edge y = 0, z = 0 one coarse step past their far end); from the sweeps
+# with the camera anywhere in the volume: 2364 (pose acceptance on its limit), 2832 and 2874 (chaotic streams, branches
+# of early stops), 3342 (singular-value cut-off on its limit), 3879 (iterations that do not settle: the rounding of
+# the sums decides)
 _FIRST = int(os.environ.get("KFH_FUZZ_FIRST", "0"))
 _SEEDS = list(range(_FIRST, _FIRST + int(os.environ.get("KFH_FUZZ_SEEDS", "16"))))
-_SEEDS += [s for s in (234, 997) if s not in _SEEDS]
+_SEEDS += [s for s in (234, 997, 2364, 2832, 2874, 3342, 3879) if s not in _SEEDS]
 
 
 @pytest.mark.parametrize("seed", _SEEDS)
@@ -66,34 +74,78 @@ def test_random_configuration(torch_cuda, seed):
     # it is not (large steps after rejected frames, voxels at the rejection thresholds, coarse volumes) they part by
     # millimetres to centimetres within a frame, and so may any other summation order.  Several directions: one
     # nudge alone can happen to leave the trajectory untouched where the others move it by millimetres.
-    nudges = [np.array(v, np.float32) * 1e-6 for v in ([1, 0, 0], [0, 1, 0], [-1, 2, -1])]
+    nudges = [np.array(v, np.float32) * 1e-6 for v in ([1, 0, 0], [0, 1, 0], [0, 0, 1], [-1, 0, 0], [1, 1, 1], [-1, 2, -1])]
+    # ... and the oracle from the unmoved start with its ICP sums taken in another order (5 or 3 strided partial
+    # rows instead of 8): a nudge translates the whole reconstruction, which tells little about the rounding of the
+    # sums; where the iterations do not settle (few valid pixels, steps of centimetres along a weak direction) that
+    # rounding is what separates two implementations.
+    variants = [(shift, 8) for shift in nudges] + [(np.zeros(3, np.float32), 5), (np.zeros(3, np.float32), 3)]
+    nudged_pos, nudged_flags = [], []                 # [variant][frame]: position relative to its start, flags
+    try:
+        for shift, rows in variants:
+            kf_ref.set_reduce_rows(rows)
+            r = kf_ref.KFusionRef(oracle_config(cfg))
+            start = pose.copy()
+            start[:3, 3] += shift
+            r.set_pose(start)
+            flags, rel = [], []
+            for i in range(n):
+                flags.append(r.process_frame(depth[i]))
+                rel.append(r.pose[:3, 3] - start[:3, 3])
+            nudged_pos.append(rel)
+            nudged_flags.append(flags)
+            r.close()
+    finally:
+        kf_ref.set_reduce_rows(8)
     ref = kf_ref.KFusionRef(oracle_config(cfg))
     ref.set_pose(pose)
-    nudged = []
-    for shift in nudges:
-        r = kf_ref.KFusionRef(oracle_config(cfg))
-        start = pose.copy()
-        start[:3, 3] += shift
-        r.set_pose(start)
-        nudged.append((r, start))
     kf = KFusion(cfg)
     kf.set_pose(pose)
     moved = False
-    yard, flags_agree = 0.0, True
+    ref_rel = []
+    flags_agree = True
     compared = 0
     for i in range(n):
         want = ref.process_frame(depth[i])
+        ref_rel.append(ref.pose[:3, 3] - pose[:3, 3])
+        if ref.cutoff_margin() < 0.03:
+            # The reference drops singular values below 1e-6 of the largest.  One of this frame's systems has one
+            # within 3 % of that limit, where the float32 sums decide by their rounding whether a barely constrained
+            # direction takes a step of centimetres or none (the smallest eigenvalue of such a system is uncertain
+            # by about a percent): from here on two summation orders are two different trajectories.
+            break
         kf.process_frame(depth[i])
         st = kf.status(i)
-        for r, start in nudged:
-            flags_agree = flags_agree and r.process_frame(depth[i]) == want
-            yard = max(yard, float(np.linalg.norm(r.pose[:3, 3] - start[:3, 3] + pose[:3, 3] - ref.pose[:3, 3])))
-        if flags_agree:
-            assert (st["tracked"], st["integrated"], st["raycasted"]) == (bool(want & 1), bool(want & 2), bool(want & 4)), (seed, i, kw)
+        flags_agree = flags_agree and all(f[i] == want for f in nudged_flags)
+        # Sensitivity up to and including this frame.  Where the stream is chaotic (a micrometre grows a hundredfold
+        # per frame: cameras at the faces of the volume that see little of the model) two implementations part ways
+        # a frame apart, so the tolerance below also admits what the nudged runs show one frame later.
+        yard = max(float(np.linalg.norm(rel[j] - ref_rel[j])) for rel in nudged_pos for j in range(i + 1))
+        got_flags = (st["tracked"], st["integrated"], st["raycasted"])
+        want_flags = (bool(want & 1), bool(want & 2), bool(want & 4))
+        if flags_agree and got_flags != want_flags:
+            # The only data-dependent flag is the acceptance of the tracked pose (rms residual <= 2e-2 and at least
+            # 15 % of the pixels valid).  A frame that sits on one of the two limits is accepted by one summation
+            # order and rejected by another; the runs are not comparable from there on.  Anything else is a defect.
+            npix = float(cfg.compute_size[0] * cfg.compute_size[1])
+            at_limit = False
+            for sums in (st["sums"], ref.reduction()):
+                rms = float(np.sqrt(sums[0] / max(float(sums[28]), 1.0)))
+                at_limit = at_limit or abs(rms - 2e-2) < 2e-3 or abs(float(sums[28]) / npix - 0.15) < 0.01
+            assert at_limit and got_flags[2] == want_flags[2], (seed, i, got_flags, want_flags, kw)
+            break
         # a level stops when its update falls below icp-threshold: whether one more iteration runs is decided at
         # rounding level, and the pose it would have added is of the size of the threshold
-        tol = 1e-3 + 3 * cfg.icp_threshold + 10 * yard
-        assert np.linalg.norm(st["pose"][:3, 3] - ref.pose[:3, 3]) < tol, (seed, i, yard, kw)
+        ahead = yard
+        if i + 1 < n:
+            # the oracle's own next position is not known yet: compare the nudged runs with each other there
+            ahead = max(ahead, max(float(np.linalg.norm(a[i + 1] - b[i + 1])) for a in nudged_pos for b in nudged_pos))
+        tol = 1e-3 + 3 * cfg.icp_threshold + 10 * ahead
+        # An early stop taken or not taken (icp-threshold) puts a run on one of two branches, and the next one
+        # splits those again: the device has to follow the oracle or one of its nudged runs, not the oracle alone.
+        hip_rel = st["pose"][:3, 3] - pose[:3, 3]
+        nearest = min(float(np.linalg.norm(hip_rel - m[i])) for m in [ref_rel] + nudged_pos)
+        assert nearest < tol, (seed, i, nearest, yard, kw)
         compared += yard < 1e-4
         moved = moved or bool(want & 1)
         if not moved and i in (3, n - 1) and not cfg.integrate_filtered:
@@ -104,6 +156,4 @@ def test_random_configuration(torch_cuda, seed):
                 assert np.array_equal(kf.download(native.BUF_MODEL_VERTEX)[..., :3], ref.model_vertex()), (seed, i, kw)
     assert compared >= 4                         # the yardstick stayed tight on the first frames at least
     ref.close()
-    for r, _ in nudged:
-        r.close()
     kf.close()
