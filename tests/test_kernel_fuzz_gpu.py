@@ -112,9 +112,67 @@ def test_integrate_and_raycast_random_case(torch_cuda, seed):
     assert np.array_equal(n_got[hit].view(np.uint32), n_want[hit].view(np.uint32)), c
 
 
+@pytest.mark.parametrize("seed", range(int(os.environ.get("KFH_KERNEL_FUZZ_SEEDS", "12"))))
+def test_track_reduce_random_case(torch_cuda, seed):
+    """trackKernel + reduceKernel on image sizes without any alignment (partial tiles of every block shape), input
+    level 0 or 1 against a full-size model map: result codes, residuals and Jacobians bit for bit, counters exact,
+    float sums within 1e-5 of the sum of absolute terms (the summation order differs)."""
+    from tests.util import pad4
+    torch = torch_cuda
+    L = native.lib()
+    rng = np.random.default_rng(9000 + seed)
+    level = int(rng.integers(0, 2))
+    iw, ih = int(rng.integers(8, 200)), int(rng.integers(6, 150))
+    rw, rh = iw << level, ih << level
+    k_ref = np.array([rw * 0.8, rw * 0.79, 0.5 * rw - 0.5, 0.5 * rh - 0.5], np.float32)
+    k_in = (k_ref / np.float32(1 << level)).astype(np.float32)
+    # model maps: the full-size depth image back-projected and moved into the world by the model pose
+    raw = kf_ref.mm2meters(make_depth(rh, rw, seed=40 + seed, holes=0.04), rw, rh, 1000.0)
+    mv_cam = kf_ref.depth2vertex(raw, kf_ref.inverse_camera_matrix(k_ref))
+    mn_cam = kf_ref.vertex2normal(mv_cam)
+    pose = _look_at(np.array([4.0, 4.0, 4.0]) + rng.uniform(-0.5, 0.5, 3), np.array([4.0, 4.0, 6.0]) + rng.uniform(-1, 1, 3),
+                    rng.uniform(-np.pi, np.pi))
+    R, t = pose[:3, :3], pose[:3, 3]
+    valid_v = mv_cam[..., 2] > 0
+    mv = np.where(valid_v[..., None], mv_cam @ R.T + t, 0).astype(np.float32)
+    valid_n = mn_cam[..., 0] != -2
+    mn = np.where(valid_n[..., None], mn_cam @ R.T, mn_cam).astype(np.float32)
+    # input maps of the level from the (half-sampled) depth
+    depth_l = raw if level == 0 else kf_ref.half_sample(raw, np.float32(0.1) * 3, 1)
+    iv = kf_ref.depth2vertex(depth_l, kf_ref.inverse_camera_matrix(k_in))
+    inn = kf_ref.vertex2normal(iv)
+    twist = np.concatenate([rng.normal(0, 0.004, 3), rng.normal(0, 0.002, 3)])
+    Ttrack = kf_ref.mat_mul(kf_ref.se3_exp(twist), pose)
+    view = kf_ref.mat_mul(kf_ref.camera_matrix(k_ref), kf_ref.mat_inverse(pose))
+    td_want = kf_ref.track(iv, inn, mv, mn, Ttrack, view)
+    sums_want = kf_ref.reduce(td_want, iw, ih)
+    t4 = [torch.from_numpy(pad4(a)).cuda() for a in (iv, inn, mv, mn)]
+    d_l = torch.from_numpy(np.ascontiguousarray(depth_l)).cuda()
+    sums = torch.empty(32, dtype=torch.float32, device="cuda")
+    td = torch.zeros((rh, rw, 8), dtype=torch.float32, device="cuda")
+    native.check(L.kfh_k_track_reduce(vp(sums), vp(td), rw, vp(d_l), hp(k_in), vp(t4[1]), iw, ih, vp(t4[2]), vp(t4[3]),
+                                      rw, rh, hp(m4(Ttrack)), hp(m4(view)), 0.1, 0.8, None))
+    td_got = td.cpu().numpy().view(kf_ref.TRACK_DTYPE).reshape(rh, rw)[:ih, :iw]
+    want = td_want[:ih, :iw]
+    assert np.array_equal(td_got["result"], want["result"]), (seed, level, iw, ih)
+    ok = want["result"] == 1
+    assert np.array_equal(td_got["error"][ok].view(np.uint32), want["error"][ok].view(np.uint32)), (seed, level, iw, ih)
+    assert np.array_equal(td_got["J"][ok].view(np.uint32), want["J"][ok].view(np.uint32)), (seed, level, iw, ih)
+    got = sums.cpu().numpy()
+    assert np.array_equal(got[28:], sums_want[28:]), (seed, level, iw, ih)
+    e = want["error"][ok].astype(np.float64)
+    J = want["J"][ok].astype(np.float64)
+    terms = [e * e] + [e * J[:, i] for i in range(6)] + [J[:, i] * J[:, j] for i in range(6) for j in range(i, 6)]
+    exact = np.array([x.sum() for x in terms])
+    mag = np.array([np.abs(x).sum() for x in terms])
+    assert np.all(np.abs(got[:28] - exact) <= 1e-5 * mag + 1e-12), (seed, level, iw, ih)
+    _seen["tracked"] = _seen.get("tracked", 0) + int(ok.mean() > 0.2)
+
+
 def test_random_cases_were_not_vacuous(torch_cuda):
     """Most drawn cameras see the surface they fuse, and most raycasts hit it."""
     if _seen["cases"] < 8:
         pytest.skip("needs the sweep above")
     assert _seen["fused"] >= 0.6 * _seen["cases"], _seen
     assert _seen["hit"] >= 0.4 * _seen["cases"], _seen
+    assert _seen.get("tracked", 0) >= 0.6 * _seen["cases"], _seen
