@@ -169,6 +169,50 @@ def test_track_reduce_random_case(torch_cuda, seed):
     _seen["tracked"] = _seen.get("tracked", 0) + int(ok.mean() > 0.2)
 
 
+@pytest.mark.parametrize("seed", range(int(os.environ.get("KFH_KERNEL_FUZZ_SEEDS", "12"))))
+def test_image_kernels_random_case(torch_cuda, seed):
+    """mm2meters (any compute-size ratio and unit), bilateral filter, robust half-sampling, depth2vertex and
+    vertex2normal on image sizes without alignment: bit-exact except the filter (1e-5 relative, holes stay holes)."""
+    torch = torch_cuda
+    L = native.lib()
+    rng = np.random.default_rng(11000 + seed)
+    ratio = int(rng.choice([1, 2, 3, 4, 8]))
+    ow, oh = int(rng.integers(5, 180)), int(rng.integers(5, 140))
+    iw, ih = ow * ratio, oh * ratio
+    divisor = float(rng.choice([1000.0, 5000.0, 1234.5]))
+    d = make_depth(ih, iw, seed=70 + seed, holes=float(rng.choice([0.0, 0.05, 0.6])))
+    raw_want = kf_ref.mm2meters(d, ow, oh, divisor)
+    filt_want = kf_ref.bilateral(raw_want)
+    d_in = torch.from_numpy(d.view(np.int16)).cuda()
+    raw = torch.empty((oh, ow), dtype=torch.float32, device="cuda")
+    filt = torch.empty((oh, ow), dtype=torch.float32, device="cuda")
+    native.check(L.kfh_k_preprocess(vp(raw), vp(filt), ow, oh, vp(d_in), iw, ih, divisor, None))
+    assert np.array_equal(raw.cpu().numpy().view(np.uint32), raw_want.view(np.uint32)), (seed, ow, oh, ratio)
+    got = filt.cpu().numpy()
+    assert np.array_equal(got == 0, filt_want == 0), (seed, ow, oh, ratio)
+    np.testing.assert_allclose(got, filt_want, rtol=1e-5, atol=0)      # the device's 2^x against the host's expf
+    # half-sampling of an even-sized image
+    hw, hh = 2 * int(rng.integers(2, 90)), 2 * int(rng.integers(2, 70))
+    src = kf_ref.mm2meters(make_depth(hh, hw, seed=90 + seed, holes=0.1), hw, hh, 1000.0)
+    half_want = kf_ref.half_sample(src, np.float32(0.1) * 3, 1)
+    half = torch.empty((hh // 2, hw // 2), dtype=torch.float32, device="cuda")
+    native.check(L.kfh_k_half_sample(vp(half), vp(torch.from_numpy(src).cuda()), hw, hh, float(np.float32(0.1) * 3), None))
+    assert np.array_equal(half.cpu().numpy().view(np.uint32), half_want.view(np.uint32)), (seed, hw, hh)
+    # vertex and normal maps
+    k = [np.float32(ow * rng.uniform(0.6, 1.1)), np.float32(ow * rng.uniform(0.6, 1.1)), np.float32(0.5 * ow - 0.5),
+         np.float32(0.5 * oh - 0.5)]
+    v_want = kf_ref.depth2vertex(raw_want, kf_ref.inverse_camera_matrix(k))
+    n_want = kf_ref.vertex2normal(v_want)
+    v = torch.empty((oh, ow, 4), dtype=torch.float32, device="cuda")
+    n = torch.empty((oh, ow, 4), dtype=torch.float32, device="cuda")
+    native.check(L.kfh_k_vertex_normal(vp(v), vp(n), vp(raw), ow, oh, *[float(x) for x in k], None))
+    v_got, n_got = v.cpu().numpy(), n.cpu().numpy()
+    assert np.array_equal(v_got[..., :3].view(np.uint32), v_want.view(np.uint32)), (seed, ow, oh)
+    invalid = n_want[..., 0] == -2
+    assert np.array_equal(n_got[..., 0] == -2, invalid), (seed, ow, oh)
+    assert np.array_equal(n_got[..., :3][~invalid].view(np.uint32), n_want[~invalid].view(np.uint32)), (seed, ow, oh)
+
+
 def test_random_cases_were_not_vacuous(torch_cuda):
     """Most drawn cameras see the surface they fuse, and most raycasts hit it."""
     if _seen["cases"] < 8:
