@@ -220,3 +220,49 @@ def test_random_cases_were_not_vacuous(torch_cuda):
     assert _seen["fused"] >= 0.6 * _seen["cases"], _seen
     assert _seen["hit"] >= 0.4 * _seen["cases"], _seen
     assert _seen.get("tracked", 0) >= 0.6 * _seen["cases"], _seen
+
+
+@pytest.mark.parametrize("res,dim", [((64, 64, 64), (4.0, 4.0, 4.0)), ((61, 45, 70), (4.0, 3.0, 5.0))])
+def test_raycast_rays_leaving_through_faces_and_edges(torch_cuda, res, dim):
+    """Cameras 0.3 m inside each face, looking out through it (and through the edges and corners next to it) with a
+    coarse step of almost five voxels: the march fetches one sample past a ray's far end, up to that many voxels
+    outside the volume on any side.  Every such fetch must stay inside the allocation (it once read 4 GiB away for
+    rows below -1) and the maps must be the oracle's."""
+    torch = torch_cuda
+    L = native.lib()
+    w, h = 96, 72
+    k = (60.0, 60.0, 47.5, 35.5)                        # wide: the rays fan out over face, edges and corners
+    vol_ref = kf_ref.new_volume(res)
+    # something to hit in the middle, so that hits and misses both occur
+    centre = 0.5 * np.asarray(dim)
+    pose0 = _look_at(centre - np.array([0.0, 0.0, 1.2]), centre, 0.3)
+    depth = np.full((h, w), 1.2, np.float32)
+    kf_ref.integrate(vol_ref, dim, depth, kf_ref.mat_inverse(pose0), kf_ref.camera_matrix(k), 0.1, 100.0)
+    vol = torch.from_numpy(vol_ref).cuda()
+    res_c, dim_c = (C.c_int32 * 3)(*res), (C.c_float * 3)(*dim)
+    step = np.float32(min(dim)) / np.float32(max(res))
+    largestep = np.float32(0.3)
+    v = torch.empty((h, w, 4), dtype=torch.float32, device="cuda")
+    n = torch.empty((h, w, 4), dtype=torch.float32, device="cuda")
+    poses = [(pose0, "inward")]                        # sees the fused surface: hits
+    for axis in range(3):
+        for side in (0, 1):
+            eye = centre.copy()
+            eye[axis] = 0.3 if side == 0 else dim[axis] - 0.3
+            target = eye.copy()
+            target[axis] += -1.0 if side == 0 else 1.0
+            for roll in (0.0, 0.7):
+                poses.append((_look_at(eye, target + np.array([0.03, 0.02, 0.01]), roll), (axis, side, roll)))
+    hits = 0
+    for pose, what in poses:
+        view = kf_ref.mat_mul(pose, kf_ref.inverse_camera_matrix(k))
+        v_want, n_want = kf_ref.raycast(vol_ref, dim, w, h, view, 0.05, 6.0, step, largestep)
+        native.check(L.kfh_k_raycast(vp(v), vp(n), w, h, vp(vol), res_c, dim_c, hp(m4(view)), 0.05, 6.0,
+                                     float(step), float(largestep), None))
+        v_got, n_got = v.cpu().numpy()[..., :3], n.cpu().numpy()[..., :3]
+        hit = n_want[..., 0] != -2
+        hits += int(hit.sum())
+        assert np.array_equal(n_got[..., 0] == -2, ~hit), what
+        assert np.array_equal(v_got.view(np.uint32), v_want.view(np.uint32)), what
+        assert np.array_equal(n_got[hit].view(np.uint32), n_want[hit].view(np.uint32)), what
+    assert hits > 1000
