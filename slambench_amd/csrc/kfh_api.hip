@@ -1052,7 +1052,7 @@ int kfh_k_raycast(void *d_vertex4, void *d_normal4, int w, int h, const void *d_
                   const float dim[3], const float view[16], float near_plane, float far_plane, float step,
                   float largestep, void *stream) {
     KFH_REQUIRE(d_vertex4 && d_normal4 && d_volume && res && dim && view, "NULL argument");
-    KFH_REQUIRE(w > 0 && h > 0 && res[0] > 0 && res[1] > 0 && res[2] > 0, "bad sizes");
+    KFH_REQUIRE(w > 0 && h > 0 && res[0] >= 2 && res[1] >= 2 && res[2] >= 2, "bad sizes (a volume side has at least two voxels)");
     KFH_REQUIRE(step > 0.f && largestep > 0.f, "steps must be positive");
     hipStream_t s = static_cast<hipStream_t>(stream);
     // scratch: [view matrix | task counter | task list]
@@ -1093,7 +1093,7 @@ int kfh_k_render_volume(uint8_t *d_rgba, int w, int h, const void *d_volume, con
                         const float view[16], float near_plane, float far_plane, float step, float largestep,
                         const float light[3], const float ambient[3], void *stream) {
     KFH_REQUIRE(d_rgba && d_volume && res && dim && view && light && ambient, "NULL argument");
-    KFH_REQUIRE(w > 0 && h > 0 && res[0] > 0 && res[1] > 0 && res[2] > 0, "bad sizes");
+    KFH_REQUIRE(w > 0 && h > 0 && res[0] >= 2 && res[1] >= 2 && res[2] >= 2, "bad sizes (a volume side has at least two voxels)");
     KFH_REQUIRE(step > 0.f && largestep > 0.f, "steps must be positive");
     hipStream_t s = static_cast<hipStream_t>(stream);
     // scratch: [view matrix | task counter | vertex map | normal map | task list]

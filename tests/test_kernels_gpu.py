@@ -405,3 +405,10 @@ def test_bad_arguments_are_rejected(torch_cuda, L):
     assert rc == 1 and b"bad argument" in L.kfh_last_error()
     rc = L.kfh_k_preprocess(vp(d), None, 6, 8, vp(d), 8, 8, 1000.0, None)
     assert rc == 1
+    # a raycast fetch takes two x-adjacent voxels: a volume one voxel thin is refused, not read past its end
+    vol = torch.zeros((4, 4, 1, 2), dtype=torch.int16, device="cuda")
+    v = torch.empty((8, 8, 4), dtype=torch.float32, device="cuda")
+    view = np.eye(4, dtype=np.float32)
+    rc = L.kfh_k_raycast(vp(v), vp(v), 8, 8, vp(vol), (C.c_int32 * 3)(1, 4, 4), (C.c_float * 3)(1.0, 1.0, 1.0),
+                         hp(m4(view)), 0.4, 4.0, 0.1, 0.1, None)
+    assert rc == 1 and b"two voxels" in L.kfh_last_error()
