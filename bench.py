@@ -5,14 +5,22 @@ One "step" = one depth frame through the whole hot path (preprocessing -> tracki
 raycasting), with the frame already resident in HBM.  Workload at N=1: BASELINE.json configs[1] —
 640x480 depth, TUM fr1 depth intrinsics, 512^3 TSDF over 8 m, ICP pyramid 10/5/4, integration-rate 2 —
 on the deterministic synthetic room stream (no dataset is available offline).  At N>1 every rank runs
-its own sequence (the reference's design-space sweeps are one process per configuration), so scaling is weak
-and there is no data-path collective.
+its own sequence (the reference's design-space sweeps are one process per configuration,
+framework/shared/src/SLAMBenchConfiguration.cpp:524-533), so scaling is weak and there is no data-path
+collective; --mode zslab shards ONE sequence's volume over the ranks instead.
+
+`--gpus N` with N > 1 started as a plain `python bench.py` (no WORLD_SIZE in the environment) launches the N
+ranks itself through torch.distributed.run before anything touches the GPU; started under torch.distributed.run
+it is one of the ranks.  The line reports the rank count the ranks counted among themselves, and the run fails
+if that is not N.
 
 Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -44,14 +52,21 @@ def parse_args():
     ap.add_argument("--host-threads", action="store_true",
                     help="with --sequences-per-gpu S: one host thread per sequence instead of one thread that "
                          "interleaves them (the library calls release the interpreter lock)")
-    ap.add_argument("--host-frames", action="store_true",
-                    help="also time the stream with frames handed over in host memory (one H2D copy per frame); "
-                         "reported as pcie_inclusive_frames_per_s, never as value")
+    ap.add_argument("--no-host-frames", action="store_true",
+                    help="skip the second leg that hands every frame over in host memory (one H2D copy per frame; "
+                         "reported as pcie_inclusive_frames_per_s, never as value)")
+    ap.add_argument("--no-dense-leg", action="store_true",
+                    help="skip the dense integration leg (roofline_dense: a volume whose every voxel is updated)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--mode", choices=["replicas", "zslab"], default="replicas",
                     help="N>1: one independent sequence per GPU (default), or ONE sequence whose volume is "
                          "sharded into z-slabs across the GPUs")
-    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (gloo for a one-GPU rehearsal)")
+    ap.add_argument("--backend", default="auto",
+                    help="torch.distributed backend: nccl (RCCL), gloo, or auto = nccl when every rank has a GPU of "
+                         "its own, gloo when ranks share GPUs (a rehearsal on a smaller box)")
+    ap.add_argument("--icp", choices=["replicated", "allreduce"], default="replicated",
+                    help="--mode zslab: every rank tracks the whole image (no collective), or every rank tracks its "
+                         "rows and the 32 ICP sums are all-reduced per iteration")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "integrate_traffic.json"),
                     help="HBM bytes per integrate launch from the committed rocprofv3 PMC passes")
     return ap.parse_args()
@@ -92,8 +107,62 @@ def cpu_baseline(cfg, depth, frames, threads):
     return frames / dt, np.stack(poses), phases / frames, threads
 
 
+def spawn_ranks(a):
+    """`python bench.py --gpus N` without a launcher: start the N ranks through torch.distributed.run and pass their
+    output and exit code on.  Called before this process has imported torch or touched the GPU, so the ranks are
+    fresh children and nothing is re-executed."""
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    return subprocess.call(cmd, env=env)
+
+
+def dense_integrate_leg(KFusion, KFusionConfig, intrinsics, V, torch):
+    """Integration of a volume whose EVERY voxel is updated: a 0.5 m cube that lies wholly inside the camera frustum,
+    one metre in front of the camera, with the seen surface (a flat wall at 3 m) far behind it.  The first four frames
+    of a sequence integrate unconditionally from the initial pose, so each of them reads and writes all V^3 voxels
+    (8 B each: the weight changes every time); timed with HIP events on the pipeline's stream like the main leg."""
+    cfg = KFusionConfig(input_size=(640, 480), intrinsics=intrinsics, volume_resolution=(V, V, V),
+                        volume_size=(0.5, 0.5, 0.5), volume_direction=(0.25, 0.25, -1.0))
+    kf = KFusion(cfg)
+    kf.set_timing(2)
+    wall = torch.full((480, 640), 3000, dtype=torch.int16, device="cuda")
+    ms, boxes = [], []
+    for rep in range(4):
+        if rep:
+            kf.reset()
+        b0, n0, vpb = kf.integrate_totals()
+        for f in range(4):
+            kf.process_frame(int(wall.data_ptr()))
+        kf.sync()
+        b1, n1, _ = kf.integrate_totals()
+        assert n1 - n0 == 4, "the first four frames of a sequence must integrate"
+        boxes.append((b1 - b0) / 4.0 * vpb)
+        # the first integration of the first repetition also pays for code loading
+        ms += [float(kf.phase_ms(f)[2]) for f in range(4) if rep or f]
+    vox = float(np.mean(boxes))
+    assert vox >= V ** 3, "the plan must keep every box of the dense volume (%g of %g voxels)" % (vox, V ** 3)
+    from slambench_amd import native
+    weights = kf.download(native.BUF_VOLUME)[..., 1]
+    assert int(weights.min()) == 4 and int(weights.max()) == 4, "every voxel must have been updated by every frame"
+    kf.close()
+    t = float(np.median(ms)) * 1e-3
+    return {"kernel": "k_integrate_plan + k_integrate", "bound": "hbm", "achieved": 8.0 * V ** 3 / t / 1e9,
+            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": 8.0 * V ** 3 / t / 1e9 / HBM_PEAK_GBS, "traffic": None,
+            "ms_per_launch": t * 1e3, "launches_timed": len(ms), "gvox_per_s": V ** 3 / t / 1e9,
+            "workload": "%d^3 voxels over a 0.5 m cube inside the frustum, wall at 3 m: all voxels read and written "
+                        "(checked: every weight == number of frames), 8 B x V^3 per launch, median HIP-event duration" % V}
+
+
 def main():
     a = parse_args()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(a))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -108,13 +177,21 @@ def main():
     from slambench_amd.metrics import ate
 
     assert torch.cuda.is_available(), "bench.py needs a HIP device"
-    device_index = local_rank % torch.cuda.device_count()
+    n_devices = torch.cuda.device_count()
+    device_index = local_rank % n_devices
     torch.cuda.set_device(device_index)
+    backend = a.backend
+    if backend == "auto":
+        backend = "nccl" if world <= n_devices else "gloo"     # RCCL wants one device per rank
+    ranks_seen = 1
     if world > 1:
-        if a.backend == "nccl":
+        if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", device_index))
         else:
-            dist.init_process_group(a.backend)
+            dist.init_process_group(backend)
+        one = torch.ones(1, dtype=torch.int64, device="cuda" if backend == "nccl" else "cpu")
+        dist.all_reduce(one)                   # the ranks count themselves
+        ranks_seen = int(one.item())
     zslab = a.mode == "zslab" and world > 1
 
     V = a.volume
@@ -133,7 +210,7 @@ def main():
 
     if zslab:
         from slambench_amd.sharded import SlabKFusion
-        sharded = SlabKFusion(cfg, rank, world, dist, torch)
+        sharded = SlabKFusion(cfg, rank, world, dist, torch, icp=a.icp)
         kf = sharded.kf
         step = sharded.process_frame
     else:
@@ -177,6 +254,7 @@ def main():
     for i in range(untimed):
         step(order[i])
     sync_all()
+    boxes0, launches0, voxels_per_box = kf.integrate_totals()
     barrier()
     if a.host_threads and extra:
         import threading
@@ -204,10 +282,11 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if a.backend == "nccl" else "cpu")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
         dist.barrier()
+    boxes1, launches1, _ = kf.integrate_totals()
 
     # integrate launches of the timed region (HIP events recorded live on the pipeline's stream)
     first = max(untimed, total - 500)
@@ -222,8 +301,11 @@ def main():
     t_int = float(integ_ms.mean()) * 1e-3 if integ_ms.size else float("nan")
     zs = kf.cfg.slab if kf.cfg.slab != (0, 0) else (0, V)
     planes = min(zs[1] + 2, V) - max(zs[0] - 2, 0) if zslab else V
-    alg_bytes = 8.0 * V * V * planes               # 4 B read + 4 B written per voxel of this device's planes
-    achieved = alg_bytes / t_int / 1e9 if integ_ms.size else None
+    # Voxels the work launches of the timed region really had to read and write: the plan launch keeps the boxes
+    # (64 x 4 x voxels_per_box / 256 voxels) that can hold a voxel integrateKernel would update; the device counts them.
+    n_int = launches1 - launches0
+    vox_per_launch = (boxes1 - boxes0) * voxels_per_box / n_int if n_int else None
+    achieved = 8.0 * vox_per_launch / t_int / 1e9 if (integ_ms.size and n_int) else None
 
     # accuracy on the forward part of the stream (ground truth is known for the synthetic camera)
     n_fwd = min(total, n_unique)
@@ -233,7 +315,7 @@ def main():
     # frames handed over in host memory (after the records of the timed region have been read: it moves the
     # context's frame counter on)
     pcie_fps = None
-    if a.host_frames and not zslab:
+    if not a.no_host_frames and not zslab:
         n_host = min(a.steps, 300)
         kf.sync()
         th = time.perf_counter()
@@ -244,20 +326,24 @@ def main():
 
     result = None
     if rank == 0:
-        traffic = None
+        traffic, traffic_source = None, None
         if os.path.exists(a.traffic_json):
             try:
                 with open(a.traffic_json) as f:
                     tj = json.load(f)
                 if int(tj.get("volume", 0)) == V:
                     traffic = tj.get("hbm_bytes_per_launch")
+                    traffic_source = ("profiles/%s: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of an earlier run of "
+                                      "this command (2 x FETCH_SIZE + WRITE_SIZE); not measured in this run"
+                                      % tj.get("source", os.path.basename(a.traffic_json)))
             except Exception:
                 traffic = None
         result = {
             "metric": "KFusion frames/s @640x480 512^3 TSDF; integrate GVox/s; ATE delta vs ref",
             "value": (1 if zslab else world * (1 + len(extra))) * a.steps / elapsed,
             "unit": "frames/s",
-            "n_gpus": world,
+            "n_gpus": ranks_seen,
+            "devices_used": min(ranks_seen, n_devices),
             "steps": a.steps,
             "warmup": a.warmup,
             "untimed_frames": untimed,
@@ -271,30 +357,37 @@ def main():
                 "workload": "KFusion 640x480 depth (TUM fr1 intrinsics), %d^3 TSDF over 8 m, ICP 10/5/4, "
                             "integration-rate 2, synthetic room stream%s" % (V, " (configs[1])" if (V == 512 and a.csr == 1) else ""),
                 "compute_size": "%dx%d" % cfg.compute_size, "volume": V,
-                "parallelism": ("one sequence, volume in %d z-slabs, raycast segments all-gathered (%s)" % (world, a.backend)
-                                if zslab else "%d sequence(s) per GPU (replicas, no collective)" % (1 + len(extra))
-                                if (world > 1 or extra) else "single GPU"),
+                "input": "every depth frame is resident in HBM before the timed region starts (value has no upload in "
+                         "it); pcie_inclusive_frames_per_s is the same stream with one host-to-device upload per frame",
+                "parallelism": ("one sequence, volume in %d z-slabs, raycast segments all-gathered, ICP %s (%s)"
+                                % (world, a.icp, backend)
+                                if zslab else "%d sequence(s) per rank (replicas, no collective; %s)" % (1 + len(extra), backend)
+                                if world > 1 else "%d sequence(s) on one GPU" % (1 + len(extra)) if extra else "single GPU"),
             },
             "integrate_gvox_per_s": (V * V * planes / t_int / 1e9) if integ_ms.size else None,
             "integrate_ms": t_int * 1e3 if integ_ms.size else None,
+            "integrate_voxels_per_launch": vox_per_launch,
+            "integrate_visited_fraction": (vox_per_launch / (V * V * planes)) if vox_per_launch else None,
             "tracked_fraction": tracked / max(1, total - first),
             "ate_rmse_m": ate_hip,
             "pcie_inclusive_frames_per_s": pcie_fps,
             "roofline": {
-                "kernel": "k_integrate",
+                "kernel": "k_integrate_plan + k_integrate",
                 "bound": "hbm",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS if integ_ms.size else None,
+                "frac": achieved / HBM_PEAK_GBS if achieved else None,
                 "traffic": traffic,
-                "traffic_gbps": (traffic / t_int / 1e9) if (traffic and integ_ms.size) else None,
-                "note": "achieved = 8 B x V^3 per integration (convention: every voxel read and written) / mean "
-                        "HIP-event duration of the integrate launches (plan + work) sampled in the timed region; "
-                        "the kernels skip voxels outside the camera frustum or behind the surface without "
-                        "touching them, so measured traffic is far below the algorithmic bytes and frac exceeds 1",
+                "traffic_source": traffic_source,
+                "note": "achieved = 8 B x the voxels of the boxes the work launch took (counted by the device; the plan "
+                        "launch drops boxes outside the camera frustum or behind the surface, which integrateKernel "
+                        "leaves untouched) / mean HIP-event duration of the two launches, sampled in the timed region; "
+                        "8 B x V^3 / that duration is integrate_gvox_per_s x 8, not a bandwidth",
             },
         }
+        if not a.no_dense_leg and not zslab and world == 1:
+            result["roofline_dense"] = dense_integrate_leg(KFusion, KFusionConfig, TUM_FR1_DEPTH_INTRINSICS, V, torch)
         if not a.no_cpu_baseline and a.cpu_frames > 0 and world == 1:
             threads = max(1, min(a.cpu_threads, os.cpu_count() or 1))
             n_cpu = min(a.cpu_frames, n_unique)
@@ -329,6 +422,10 @@ def main():
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(result))
+    if ranks_seen != a.gpus:
+        sys.stderr.write("bench.py: --gpus %d but %d rank(s) took part (WORLD_SIZE=%s)\n"
+                         % (a.gpus, ranks_seen, os.environ.get("WORLD_SIZE")))
+        sys.exit(3)
 
 
 if __name__ == "__main__":

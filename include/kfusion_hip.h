@@ -28,6 +28,11 @@
  *     that device current for its own duration and restores the caller's, so contexts of several
  *     devices can be driven from one thread or from one thread each.  Calls on ONE context must not
  *     overlap; calls on different contexts may (kfh_last_error() is per thread);
+ *   - the staged calls follow Kfusion's order (kfh_preprocess, kfh_track, kfh_integrate, kfh_raycast,
+ *     kfh_end_frame); kfh_integrate and kfh_raycast may also be repeated or called after kfh_set_pose without
+ *     a kfh_track in between (a second fusion of the same depth map, a re-render from another pose): each launch
+ *     then empties its own work list first, and the raycast makes its pose the one tracking will read the
+ *     model maps with;
  *   - everything is queued on the context's stream and nothing waits unless said so.  The second
  *     pass of a frame's raycast may stay unqueued until the next frame's preprocessing (it then
  *     shares that launch) or until a call that reads the model maps, waits for the stream, returns
@@ -139,6 +144,11 @@ int kfh_get_pose(kfh_context *ctx, float pose[16]);                    /* synchr
 int kfh_set_pose(kfh_context *ctx, const float pose[16]);
 int kfh_get_status(kfh_context *ctx, int frame, kfh_frame_status *out); /* synchronises; last 4096 frames kept */
 int kfh_frame_index(kfh_context *ctx, int *frame);
+/* Running totals of the integration's work list since kfh_create / kfh_reset: boxes of voxels_per_box voxels
+ * (64 x 4 x a z extent chosen from the volume height) that the plan launches kept because they can hold a voxel
+ * integrateKernel would update, and integrations that actually ran.  boxes * voxels_per_box * 8 bytes is what the
+ * work launches had to read and write at most; a benchmark takes the difference of two calls.  Synchronises. */
+int kfh_integrate_totals(kfh_context *ctx, uint64_t *boxes, uint64_t *launches, int32_t *voxels_per_box);
 int kfh_compute_size(kfh_context *ctx, int *w, int *h);
 int kfh_download(kfh_context *ctx, int buffer, int level, void *h_dst, size_t bytes);
 int kfh_device_ptr(kfh_context *ctx, int buffer, int level, void **d_ptr, size_t *bytes);

@@ -85,6 +85,14 @@ struct kfh_context {
     bool pre_pending = false;              // the main stream has not yet waited for ev_pre_done
     bool overlap = false;
     bool tail_pending = false;             // the second pass of the last raycast has not been launched yet
+    // The tracking finish kernel is what empties the two device work lists (integrate boxes, unfinished rays) and
+    // points the raycast matrices at the pose it accepted.  A staged call made without a kfh_track in between
+    // (a second kfh_integrate, kfh_set_pose + kfh_raycast to re-render) finds these false and does both itself.
+    // The unsharded raycast only writes the packed map tracking reads; the float4 vertex / normal maps and the hit
+    // distances are built from it when a caller asks for them (model_maps_stale: not built since the last raycast).
+    bool model_maps_stale = false;
+    bool box_list_fresh = false;
+    bool ray_list_fresh = false;
     float4 *d_in_vertex[3] = {nullptr, nullptr, nullptr};
     float4 *d_in_normal[3] = {nullptr, nullptr, nullptr};
     float4 *d_vertex = nullptr, *d_normal = nullptr;
@@ -210,6 +218,7 @@ int init_state(kfh_context *c) {
     KFH_HIP(hipStreamSynchronize(c->stream));
     c->pre_pending = false;
     c->tail_pending = false;       // the maps it would complete are about to be cleared
+    c->model_maps_stale = false;
     c->next_set = 0;
     select_set(c, 0);
     KFH_HIP(launch_fill_volume(c->d_volume, c->volume_voxels, c->stream));
@@ -229,6 +238,7 @@ int init_state(kfh_context *c) {
     KFH_HIP(hipMemcpyAsync(c->d_ctrl, &init, sizeof(Ctrl), hipMemcpyHostToDevice, c->stream));
     KFH_HIP(hipStreamSynchronize(c->stream));   // `init` lives on this stack frame
     KFH_HIP(launch_pose_derive(c->d_ctrl, c->k, 1, c->stream));
+    c->box_list_fresh = c->ray_list_fresh = true;
     c->frame = 0;
     c->d_depth_cur = c->d_depth_in[0];
     c->upload_slot = 0;
@@ -389,7 +399,7 @@ int kfh_upload_depth(kfh_context *c, const uint16_t *h_depth) {
     // The copy goes on the stream that preprocesses.  The slot's pinned buffer fed the copy of the frame before
     // the previous one and its device buffer that frame's preprocessing launch: wait for that launch only, so the
     // host fills this slot while the device is still busy with the previous frame.
-    hipStream_t ps = c->overlap ? c->pre_stream : c->stream;
+    hipStream_t ps = (c->overlap && c->timing != 1) ? c->pre_stream : c->stream;   // the stream kfh_preprocess will use
     const int slot = c->upload_slot;
     c->upload_slot ^= 1;
     if (c->slot_unread[slot]) KFH_HIP(hipStreamSynchronize(ps));   // two uploads ago nobody consumed this slot
@@ -498,6 +508,7 @@ int kfh_track(kfh_context *c) {
         }
         KFH_HIP(launch_icp_finish(finish_args(c, seq, rows), c->stream));
     }
+    c->box_list_fresh = c->ray_list_fresh = true;      // both finish kernels empty the lists and set the raycast matrices
     if (timed_frame(c)) KFH_HIP(hipEventRecord(c->ev[c->frame % KFH_TIMING_RING][2], c->stream));
     return KFH_OK;
 }
@@ -515,11 +526,15 @@ int kfh_integrate(kfh_context *c) {
     KFH_HIP(ensure_pre_done(c));
     if ((c->frame % c->cfg.integration_rate) == 0 || c->frame <= 3) {
         const float *src = c->cfg.integrate_filtered ? c->d_scaled[0] : c->d_float_depth;
+        if (!c->box_list_fresh)      // no kfh_track since the last integration: the list still holds that one's boxes
+            KFH_HIP(hipMemsetAsync(&c->d_ctrl->integrate_box_count, 0, sizeof(unsigned), c->stream));
+        c->box_list_fresh = false;
         // planes [zs0, zs1) are stored; the kernel replays the z < zs0 steps of each column arithmetically
         KFH_HIP(launch_integrate(c->d_volume, c->cfg.vol_res, c->cfg.vol_dim, c->zs0, c->zs1, src, c->w, c->h,
                                  &c->d_ctrl->inv_pose, camera_matrix(c->k[0], c->k[1], c->k[2], c->k[3]),
                                  c->cfg.mu, MAX_WEIGHT, &c->d_ctrl->integrate_gate, c->d_integrate_boxes,
-                                 &c->d_ctrl->integrate_box_count, c->d_bricks, tile_max_for_integrate(c), c->stream));
+                                 &c->d_ctrl->integrate_box_count, c->d_bricks, tile_max_for_integrate(c), c->stream,
+                                 &c->d_ctrl->integrate_boxes_total));
     }
     if (timed_frame(c)) {
         KFH_HIP(hipEventRecord(c->ev[c->frame % KFH_TIMING_RING][3], c->stream));
@@ -541,7 +556,10 @@ static float raycast_step(const kfh_config &cfg) {
 // and shares that launch.  Every entry point that reads the maps, waits for the stream, hands out pointers or
 // changes what the pass reads (pose, volume, task list) launches a postponed pass first (flush_tail).
 static hipError_t raycast_part(kfh_context *c, int part, const PreprocessLaunch *pre) {
-    return launch_raycast_part(c->d_vertex, c->d_normal, c->d_ray_t, c->d_ref_tn, c->w, c->h, c->d_volume, c->cfg.vol_res,
+    static const bool eager = std::getenv("KFH_EAGER_MODEL_MAPS") != nullptr;     // experiments: all four maps per raycast
+    c->model_maps_stale = !eager;
+    return launch_raycast_part(eager ? c->d_vertex : nullptr, eager ? c->d_normal : nullptr, eager ? c->d_ray_t : nullptr,
+                               c->d_ref_tn, c->w, c->h, c->d_volume, c->cfg.vol_res,
                                c->cfg.vol_dim, 0, c->cfg.vol_res[2], &c->d_ctrl->view, NEAR_PLANE, FAR_PLANE,
                                raycast_step(c->cfg), 0.75f * c->cfg.mu, c->d_ray_tasks, &c->d_ctrl->ray_task_count,
                                c->d_bricks, part, pre, c->stream);
@@ -560,11 +578,24 @@ static int flush_tail(kfh_context *c) {
     return KFH_OK;
 }
 
+// Before a raycast launch: the list of unfinished rays must be empty and the matrices tracking rebuilds the model
+// vertices from (raycast_pose, raycast_view, project_ref) must be those of the pose that is rendered.  The tracking
+// finish kernel has done both for the first raycast after a kfh_track; any other gets them done here.
+static int prepare_ray_list(kfh_context *c) {
+    if (!c->ray_list_fresh) {
+        KFH_HIP(hipMemsetAsync(&c->d_ctrl->ray_task_count, 0, sizeof(unsigned), c->stream));
+        KFH_HIP(launch_pose_derive(c->d_ctrl, c->k, 1, c->stream));
+    }
+    c->ray_list_fresh = false;
+    return KFH_OK;
+}
+
 int kfh_raycast(kfh_context *c) {
     KFH_REQUIRE(c != nullptr, "context is NULL");
     DeviceScope on_device(c->device);
     if (int rc = flush_tail(c)) return rc;
     if (c->frame > 2 && !c->sharded) {
+        if (int rc = prepare_ray_list(c)) return rc;
         if (tail_may_wait(c)) {
             KFH_HIP(raycast_part(c, RAYCAST_MARCH, nullptr));
             c->tail_pending = true;
@@ -584,6 +615,7 @@ int kfh_raycast_slab(kfh_context *c) {
     DeviceScope on_device(c->device);
     if (int rc = flush_tail(c)) return rc;
     if (c->frame > 2) {
+        if (int rc = prepare_ray_list(c)) return rc;
         KFH_HIP(launch_raycast(c->d_vertex, c->d_normal, c->d_ray_t, nullptr, c->w, c->h, c->d_volume,
                                c->cfg.vol_res, c->cfg.vol_dim, c->cfg.slab_z0, c->cfg.slab_z1, &c->d_ctrl->view, NEAR_PLANE,
                                FAR_PLANE, raycast_step(c->cfg), 0.75f * c->cfg.mu, c->d_ray_tasks,
@@ -722,6 +754,7 @@ int kfh_set_pose(kfh_context *c, const float pose[16]) {
     KFH_HIP(hipMemcpyAsync(&c->d_ctrl->pose, pose, sizeof(Mat4), hipMemcpyHostToDevice, c->stream));
     KFH_HIP(hipStreamSynchronize(c->stream));
     KFH_HIP(launch_pose_derive(c->d_ctrl, c->k, 0, c->stream));
+    c->ray_list_fresh = false;     // a raycast that follows renders from this pose, not from the tracked one
     return KFH_OK;
 }
 
@@ -734,6 +767,18 @@ int kfh_get_status(kfh_context *c, int frame, kfh_frame_status *out) {
     KFH_HIP(hipMemcpyAsync(out, c->d_status + (frame % KFH_STATUS_RING), sizeof(kfh_frame_status),
                            hipMemcpyDeviceToHost, c->stream));
     KFH_HIP(hipStreamSynchronize(c->stream));
+    return KFH_OK;
+}
+
+int kfh_integrate_totals(kfh_context *c, uint64_t *boxes, uint64_t *launches, int32_t *voxels_per_box) {
+    KFH_REQUIRE(c != nullptr && boxes != nullptr && launches != nullptr && voxels_per_box != nullptr, "NULL argument");
+    DeviceScope on_device(c->device);
+    unsigned long long t[2] = {0, 0};
+    KFH_HIP(hipMemcpyAsync(t, &c->d_ctrl->integrate_boxes_total, sizeof(t), hipMemcpyDeviceToHost, c->stream));
+    KFH_HIP(hipStreamSynchronize(c->stream));
+    *boxes = t[0];
+    *launches = t[1];
+    *voxels_per_box = integrate_box_voxels(c->zs1);
     return KFH_OK;
 }
 
@@ -774,10 +819,18 @@ int kfh_device_ptr(kfh_context *c, int buffer, int level, void **d_ptr, size_t *
             *d_ptr = buffer == KFH_BUF_INPUT_VERTEX ? (void *)c->d_in_vertex[level] : (void *)c->d_in_normal[level];
             *bytes = nl * sizeof(float4);
             break;
-        case KFH_BUF_MODEL_VERTEX: *d_ptr = c->d_vertex; *bytes = npix * sizeof(float4); break;
-        case KFH_BUF_MODEL_NORMAL: *d_ptr = c->d_normal; *bytes = npix * sizeof(float4); break;
+        case KFH_BUF_MODEL_VERTEX:
+        case KFH_BUF_MODEL_NORMAL:
+        case KFH_BUF_RAY_T:
+            if (c->model_maps_stale) {
+                KFH_HIP(launch_model_maps(c->d_vertex, c->d_normal, c->d_ray_t, c->d_ref_tn, &c->d_ctrl->raycast_view, c->w,
+                                          c->h, c->stream));
+                c->model_maps_stale = false;
+            }
+            if (buffer == KFH_BUF_RAY_T) { *d_ptr = c->d_ray_t; *bytes = npix * sizeof(float); }
+            else { *d_ptr = buffer == KFH_BUF_MODEL_VERTEX ? c->d_vertex : c->d_normal; *bytes = npix * sizeof(float4); }
+            break;
         case KFH_BUF_VOLUME: *d_ptr = c->d_volume; *bytes = c->volume_voxels * sizeof(short2); break;
-        case KFH_BUF_RAY_T: *d_ptr = c->d_ray_t; *bytes = npix * sizeof(float); break;
         case KFH_BUF_BRICK_MARKS:
             if (!c->d_bricks) return fail(KFH_ERR_STATE, "this context keeps no brick marks (sharded volume)");
             *d_ptr = c->d_bricks;
@@ -890,6 +943,7 @@ int kfh_debug_integrate_stats(kfh_context *c, unsigned long long *h_out, size_t 
     KFH_HIP(hipMemset(d, 0, n_values * sizeof(unsigned long long)));
     KFH_HIP(hipMemsetAsync(&c->d_ctrl->integrate_box_count, 0, sizeof(unsigned), c->stream));
     set_integrate_debug(d);
+    c->box_list_fresh = false;
     const float *src = c->cfg.integrate_filtered ? c->d_scaled[0] : c->d_float_depth;
     hipError_t e = launch_integrate(c->d_volume, c->cfg.vol_res, c->cfg.vol_dim, c->zs0, c->zs1, src, c->w, c->h,
                                     &c->d_ctrl->inv_pose, camera_matrix(c->k[0], c->k[1], c->k[2], c->k[3]),
@@ -920,6 +974,7 @@ int kfh_debug_raycast_stats(kfh_context *c, unsigned long long *h_out) {
     KFH_HIP(hipMemset(d, 0, n * sizeof(unsigned long long)));
     KFH_HIP(hipMemsetAsync(&c->d_ctrl->ray_task_count, 0, sizeof(unsigned), c->stream));
     set_raycast_debug(d);
+    c->ray_list_fresh = false;
     hipError_t e = launch_raycast(c->d_vertex, c->d_normal, c->d_ray_t, c->d_ref_tn, c->w, c->h, c->d_volume,
                                   c->cfg.vol_res, c->cfg.vol_dim, 0, c->cfg.vol_res[2], &c->d_ctrl->view, NEAR_PLANE,
                                   FAR_PLANE, raycast_step(c->cfg), 0.75f * c->cfg.mu, c->d_ray_tasks,

@@ -40,6 +40,10 @@ struct Ctrl {
     unsigned ray_task_count;  // rays the first raycast pass handed to the second (reset by the tracking finish)
     unsigned integrate_box_count;  // boxes the integrate plan launch kept (reset by the tracking finish)
     int pad_[3];
+    // running totals since the context was created or reset (never cleared by the frame kernels): boxes the plan
+    // launches kept, and plan launches whose gate was open.  A benchmark reads them before and after a run.
+    unsigned long long integrate_boxes_total;
+    unsigned long long integrate_launches_total;
     IcpState icp[2];    // alternating records of the ICP loop
 };
 
@@ -160,14 +164,19 @@ size_t integrate_box_list_bytes(const int res[3], int z1);
 hipError_t launch_integrate(short2 *vol, const int res[3], const float dim[3], int z0, int z1,
                             const float *depth, int w, int h, const Mat4 *inv_track, Mat4 K, float mu,
                             float maxweight, const int *gate, unsigned *boxes, unsigned *box_count,
-                            unsigned char *bricks, const float *tile_max, hipStream_t s);
+                            unsigned char *bricks, const float *tile_max, hipStream_t s,
+                            unsigned long long *totals = nullptr);   // {boxes kept, launches with an open gate} += ...
+// voxels of one box of the integrate work list for a volume whose last stored plane is z1 - 1
+int integrate_box_voxels(int z1);
 // One byte per 8^3-voxel brick ("nothing a coarse raycast step could notice in here"): integrate clears marks,
 // raycast skips marked bricks.  Optional (null) in both launches; whole volumes only.
 inline size_t brick_mark_bytes(const int res[3]) {
     return (size_t)((res[0] + 7) / 8) * ((res[1] + 7) / 8) * ((res[2] + 7) / 8);
 }
 // Two launches: per-pixel march, then the rays it left unfinished.  `tasks` holds raycast_task_bytes(w, h)
-// bytes and *task_count must be zero when the first launch starts.
+// bytes and *task_count must be zero when the first launch starts.  Of the four output maps only those given
+// (non-null) are written; launch_model_maps rebuilds vertex, normal and ray_t from ref_tn and the view matrix the
+// raycast used.
 size_t raycast_task_bytes(int w, int h);
 hipError_t launch_raycast(float4 *vertex, float4 *normal, float *ray_t, float4 *ref_tn, int w, int h,
                           const short2 *vol, const int res[3], const float dim[3], int z0, int z1, const Mat4 *view,
@@ -193,6 +202,8 @@ hipError_t launch_raycast_part(float4 *vertex, float4 *normal, float *ray_t, flo
                                const Mat4 *view, float near_plane, float far_plane, float step, float largestep,
                                void *tasks, unsigned *task_count, const unsigned char *bricks, int part,
                                const PreprocessLaunch *with_preprocess, hipStream_t s);
+hipError_t launch_model_maps(float4 *vertex, float4 *normal, float *ray_t, const float4 *ref_tn, const Mat4 *view,
+                             int w, int h, hipStream_t s);
 hipError_t launch_composite(float4 *vertex, float4 *normal, float *ray_t, float4 *ref_tn, const float *t_parts,
                             const float4 *v_parts, const float4 *n_parts, int n_parts_count, int npix,
                             hipStream_t s);

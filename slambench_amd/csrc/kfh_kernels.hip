@@ -1322,7 +1322,8 @@ __device__ inline void finish_tracking_wave(const FinishArgs &a, Mat4 pose, cons
     for (int d = lane; d < KFH_CTRL_HEAD_DWORDS; d += 64) {
         const bool raycast_field = (d >= KFH_CTRL_DW(raycast_pose) && d < KFH_CTRL_DW(inv_pose)) ||
                                    (d >= KFH_CTRL_DW(raycast_view) && d < KFH_CTRL_DW(sums));
-        if (rc || !raycast_field) c[d] = ctrl_img[d];
+        const bool running_total = d >= KFH_CTRL_DW(integrate_boxes_total) && d < KFH_CTRL_DW(icp);
+        if ((rc || !raycast_field) && !running_total) c[d] = ctrl_img[d];
     }
     if (a.status_ring) {
         unsigned *st = reinterpret_cast<unsigned *>(a.status_ring + (a.frame % KFH_STATUS_RING));
@@ -1513,6 +1514,7 @@ struct IntegrateArgs {
     int bgx, bgy;               //   below RAY_COARSE_SAFE since the last reset; may be null
     const float *tile_max;      // largest depth per preprocessing tile (PRE_TX x PRE_TY pixels, apron included); may be null
     int tiles_x, tiles_y;
+    unsigned long long *totals; // {boxes kept, launches with an open gate} running totals; may be null
     unsigned long long *dbg;
 };
 
@@ -1604,13 +1606,17 @@ __device__ inline bool box_misses_frustum(const IntegrateArgs &a, const Mat4 &in
 // of dispatching a workgroup per box of the whole volume.
 constexpr int KFH_PLAN_TILES_PER_THREAD = 8;
 constexpr int KFH_PLAN_MAX_TILES = 256 * KFH_PLAN_TILES_PER_THREAD;     // depth tiles a plan block holds in LDS (640 x 480: 1200)
+// cells of 4 x 4 tiles a plan block holds; narrow, tall images have more cells per tile (160 x 3272 pixels: 5 x 409
+// tiles make 2 x 103 cells), so the depth test is only taken when the cells fit
+constexpr int KFH_PLAN_COARSE_CELLS = KFH_PLAN_MAX_TILES / 16 + 64;
 template <int INTEGRATE_GROUP>     // boxes per work item (consecutive in z): 1, 2 or 4 (mask bits of the packed item)
 __global__ __launch_bounds__(256) void k_integrate_plan(IntegrateArgs a) {
     __shared__ float tile_max_lds[KFH_PLAN_MAX_TILES];
-    __shared__ float coarse_max_lds[KFH_PLAN_MAX_TILES / 16 + 64];     // maxima of 4 x 4 tiles
+    __shared__ float coarse_max_lds[KFH_PLAN_COARSE_CELLS];            // maxima of 4 x 4 tiles
     // everything the block reads from memory is requested at once, the gate included
     const int ntiles = a.tiles_x * a.tiles_y;
-    const bool depth_test = a.tile_max != nullptr && ntiles <= KFH_PLAN_MAX_TILES && a.tiles_x <= 64;
+    const bool depth_test = a.tile_max != nullptr && ntiles <= KFH_PLAN_MAX_TILES && a.tiles_x <= 64 &&
+                            ((a.tiles_x + 3) >> 2) * ((a.tiles_y + 3) >> 2) <= KFH_PLAN_COARSE_CELLS;
     float tm[KFH_PLAN_TILES_PER_THREAD];
 #pragma unroll
     for (int k = 0; k < KFH_PLAN_TILES_PER_THREAD; ++k)
@@ -1618,6 +1624,7 @@ __global__ __launch_bounds__(256) void k_integrate_plan(IntegrateArgs a) {
     const Mat4 inv_track = *a.inv_track;
     const int gate = a.gate ? *a.gate : 1;
     if (gate == 0) return;
+    if (a.totals && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(a.totals + 1, 1ull);
     if (depth_test) {
 #pragma unroll
         for (int k = 0; k < KFH_PLAN_TILES_PER_THREAD; ++k) tile_max_lds[threadIdx.x + 256 * k] = tm[k];
@@ -1665,7 +1672,10 @@ __global__ __launch_bounds__(256) void k_integrate_plan(IntegrateArgs a) {
         const unsigned long long lm = __ballot(leader);
         const int first = __ffsll((long long)lm) - 1;
         unsigned base = 0;
-        if (lane == first) base = atomicAdd(a.box_count, (unsigned)__popcll(lm));
+        if (lane == first) {
+            base = atomicAdd(a.box_count, (unsigned)__popcll(lm));
+            if (a.totals) atomicAdd(a.totals, (unsigned long long)__popcll(m));
+        }
         base = __builtin_amdgcn_readlane(base, first);
         if (leader)
             a.boxes[base + __popcll(lm & ((1ull << lane) - 1ull))] =
@@ -1849,6 +1859,8 @@ static int integrate_group(int z1) {
     return z1 <= 1024 ? 1 : 4;
 }
 
+int integrate_box_voxels(int z1) { return 64 * 4 * integrate_zchunk(z1); }
+
 size_t integrate_box_list_bytes(const int res[3], int z1) {
     const int zchunk = integrate_zchunk(z1);
     return (size_t)((res[0] + 63) / 64) * ((res[1] + 3) / 4) * ((z1 + zchunk - 1) / zchunk) * sizeof(unsigned);
@@ -1857,7 +1869,8 @@ size_t integrate_box_list_bytes(const int res[3], int z1) {
 hipError_t launch_integrate(short2 *vol, const int res[3], const float dim[3], int z0, int z1,
                             const float *depth, int w, int h, const Mat4 *inv_track, Mat4 K, float mu,
                             float maxweight, const int *gate, unsigned *boxes, unsigned *box_count,
-                            unsigned char *bricks, const float *tile_max, hipStream_t s) {
+                            unsigned char *bricks, const float *tile_max, hipStream_t s,
+                            unsigned long long *totals) {
     // Short z chunks: boxes that miss the camera frustum never reach the work launch, the others replay the
     // column prefix (a few packed adds per step) and then march only zchunk steps, so no wavefront runs long.
     IntegrateArgs a;
@@ -1872,6 +1885,7 @@ hipError_t launch_integrate(short2 *vol, const int res[3], const float dim[3], i
     a.boxes = boxes; a.box_count = box_count;
     a.bricks = bricks; a.bgx = (res[0] + 7) / 8; a.bgy = (res[1] + 7) / 8;
     a.tile_max = tile_max; a.tiles_x = (w + PRE_TX - 1) / PRE_TX; a.tiles_y = (h + PRE_TY - 1) / PRE_TY;
+    a.totals = totals;
     a.dbg = g_integrate_debug;
     const int group = integrate_group(z1);
     const int groups = (a.gz + group - 1) / group;
@@ -2136,8 +2150,10 @@ __device__ inline void finish_ray(const VolDev<POW2, OFFW> &vol, f3 origin, f3 d
             nrm = make_float4(n.x, n.y, n.z, 0.f);
         }
     }
-    vertex[o] = vtx;
-    normal[o] = nrm;
+    // the float4 maps are for callers; the pipeline's own raycast leaves them out (null) and has them built from
+    // the packed map when somebody asks (k_model_maps)
+    if (vertex) vertex[o] = vtx;
+    if (normal) normal[o] = nrm;
     if (ray_t) ray_t[o] = hitv.w > 0.0f ? hitv.w : 0.f;
     // packed model map for tracking: hit distance + normal (the vertex is origin + direction * t)
     if (ref_tn) ref_tn[o] = make_float4(hitv.w > 0.0f ? hitv.w : 0.f, nrm.x, nrm.y, nrm.z);
@@ -2606,6 +2622,32 @@ hipError_t launch_composite(float4 *vertex, float4 *normal, float *ray_t, float4
                             const float4 *v_parts, const float4 *n_parts, int n, int npix, hipStream_t s) {
     hipLaunchKernelGGL(k_composite, dim3((npix + 255) / 256), dim3(256), 0, s, vertex, normal, ray_t, ref_tn, t_parts,
                        v_parts, n_parts, n, npix);
+    return hipGetLastError();
+}
+
+// Vertex, normal and hit-distance maps of the last raycast rebuilt from the packed map {t, normal}: the raycast
+// stored vertex = origin + direction * t with direction = rotate(view, (x, y, 1)); the same expressions on the same
+// matrix give the same bits, so a caller sees exactly what the raycast would have written.
+__global__ __launch_bounds__(256) void k_model_maps(float4 *__restrict__ vertex, float4 *__restrict__ normal,
+                                                    float *__restrict__ ray_t, const float4 *__restrict__ ref_tn,
+                                                    const Mat4 *__restrict__ view_p, int w, int h) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= w || y >= h) return;
+    const Mat4 view = *view_p;
+    const f3 origin = mk3(view.m[3], view.m[7], view.m[11]);
+    const f3 direction = rotate(view, mk3((float)x, (float)y, 1.f));
+    const int o = x + y * w;
+    const float4 tn = ref_tn[o];
+    const f3 p = origin + direction * tn.x;
+    vertex[o] = tn.x > 0.0f ? make_float4(p.x, p.y, p.z, 0.f) : make_float4(0.f, 0.f, 0.f, 0.f);
+    normal[o] = make_float4(tn.y, tn.z, tn.w, 0.f);
+    ray_t[o] = tn.x;
+}
+
+hipError_t launch_model_maps(float4 *vertex, float4 *normal, float *ray_t, const float4 *ref_tn, const Mat4 *view,
+                             int w, int h, hipStream_t s) {
+    hipLaunchKernelGGL(k_model_maps, dim3((w + 63) / 64, (h + 3) / 4), dim3(256), 0, s, vertex, normal, ray_t, ref_tn,
+                       view, w, h);
     return hipGetLastError();
 }
 

@@ -118,6 +118,12 @@ class KFusion:
             "icp_iterations": st.icp_iterations, "slow_solves": st.slow_solves,
         }
 
+    def integrate_totals(self):
+        """(boxes kept by the integration plans, integrations run, voxels per box) since creation / reset."""
+        b, n, v = C.c_uint64(), C.c_uint64(), C.c_int32()
+        native.check(self._L.kfh_integrate_totals(self._ctx, C.byref(b), C.byref(n), C.byref(v)))
+        return b.value, n.value, v.value
+
     def trajectory(self, first=0, count=None):
         n = self.frame
         if count is None:

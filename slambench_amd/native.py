@@ -23,7 +23,7 @@ EXPORTED_SYMBOLS = (
     "kfh_upload_depth", "kfh_set_depth_device",
     "kfh_preprocess", "kfh_track", "kfh_integrate", "kfh_raycast", "kfh_end_frame", "kfh_process_frame",
     "kfh_sync",
-    "kfh_get_pose", "kfh_set_pose", "kfh_get_status", "kfh_frame_index", "kfh_compute_size",
+    "kfh_get_pose", "kfh_set_pose", "kfh_get_status", "kfh_frame_index", "kfh_integrate_totals", "kfh_compute_size",
     "kfh_download", "kfh_device_ptr", "kfh_stream", "kfh_set_timing", "kfh_phase_ms", "kfh_phase_ms_frame",
     "kfh_raycast_slab", "kfh_composite_slabs",
     "kfh_render", "kfh_render_device", "kfh_enable_track_render",
@@ -71,6 +71,7 @@ def lib():
         "kfh_get_pose": [vp, vp], "kfh_set_pose": [vp, vp],
         "kfh_get_status": [vp, i32, C.POINTER(FrameStatus)],
         "kfh_frame_index": [vp, C.POINTER(C.c_int)],
+        "kfh_integrate_totals": [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_int32)],
         "kfh_compute_size": [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)],
         "kfh_download": [vp, i32, i32, vp, C.c_size_t],
         "kfh_device_ptr": [vp, i32, i32, C.POINTER(vp), C.POINTER(C.c_size_t)],

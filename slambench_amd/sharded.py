@@ -55,9 +55,12 @@ class SlabKFusion:
     """One rank's share of a sharded KinectFusion run.  `dist` is torch.distributed (already initialised)
     or None for a single process that owns the whole volume."""
 
-    def __init__(self, cfg: KFusionConfig, rank=0, world_size=1, dist=None, torch=None):
+    def __init__(self, cfg: KFusionConfig, rank=0, world_size=1, dist=None, torch=None, icp="replicated"):
+        if icp not in ("replicated", "allreduce"):
+            raise ValueError("icp must be 'replicated' or 'allreduce'")
         self.rank, self.world = rank, world_size
         self.dist, self.torch = dist, torch
+        self.icp = icp if world_size > 1 else "replicated"
         z0, z1 = slab_bounds(cfg.volume_resolution[2], world_size, rank)
         self.cfg = KFusionConfig(**{**cfg.__dict__, "slab": (z0, z1) if world_size > 1 else (0, 0)})
         self.kf = KFusion(self.cfg)

@@ -428,3 +428,63 @@ def test_contexts_driven_from_concurrent_threads(torch_cuda):
         for traj, vol in together[i]:
             assert np.array_equal(traj, alone[i][0])
             assert np.array_equal(vol, alone[i][1])
+
+
+def test_staged_calls_outside_the_frame_order(torch_cuda):
+    """kfh_raycast and kfh_integrate without a kfh_track in between: a re-render after kfh_set_pose (twice in a
+    row) gives the oracle's raycast of the same volume from that pose, tracking afterwards reads the model maps
+    with the pose they were rendered from, and a repeated kfh_integrate fuses the depth map exactly once more."""
+    cfg = KFusionConfig(compute_size_ratio=2, volume_resolution=(128, 128, 128))
+    depth, gt, ts = synth.make_sequence(10, seed=1)
+    kf = KFusion(cfg)
+    for i in range(6):
+        kf.process_frame(depth[i])
+    w, h = cfg.compute_size
+    vol = kf.download(native.BUF_VOLUME)
+    step = float(np.float32(min(cfg.volume_size)) / np.float32(max(cfg.volume_resolution)))
+    large = float(np.float32(0.75) * np.float32(cfg.mu))
+    # an emptyish view (turned away from the room's nearest wall) hands nearly every ray to the second pass
+    for twist in ([0.05, -0.03, 0.02, 0.0, 0.04, -0.02], [0.3, 0.1, -0.2, 0.1, 0.9, 0.0]):
+        q = kf_ref.mat_mul(kf.pose, kf_ref.se3_exp(np.array(twist)))
+        kf.set_pose(q)
+        view = kf_ref.mat_mul(q, kf_ref.inverse_camera_matrix(cfg.camera))
+        want_v, want_n = kf_ref.raycast(vol.copy(), cfg.volume_size, w, h, view, 0.4, 4.0, step, large)
+        for _ in range(2):
+            kf.raycasting()
+            got_v = kf.download(native.BUF_MODEL_VERTEX)[..., :3]
+            got_n = kf.download(native.BUF_MODEL_NORMAL)[..., :3]
+            assert np.array_equal(got_v, want_v)
+            hit = want_n[..., 0] != -2
+            assert np.array_equal(got_n[..., 0] != -2, hit)
+            assert np.array_equal(got_n[hit], want_n[hit])
+    # back at the tracked pose: re-render, then the next frames track against that render as if nothing had happened
+    ref = KFusion(cfg)
+    for i in range(6):
+        ref.process_frame(depth[i])
+    kf.set_pose(ref.pose)
+    kf.raycasting()
+    for i in range(6, 10):
+        kf.process_frame(depth[i])
+        ref.process_frame(depth[i])
+    assert all(kf.status(f)["tracked"] for f in range(6, 10))
+    assert np.array_equal(kf.trajectory(6), ref.trajectory(6))
+    # Frame 10 in stages, with the integration repeated on one of the two contexts: every call fuses the depth map
+    # exactly once more (the box list is emptied per launch, so a repeat does not also replay the previous list)
+    vols = []
+    for k, repeats in ((kf, 1), (ref, 3)):
+        k.set_depth(depth[9])          # the stream's last frame again: any depth map will do
+        k.preprocessing()
+        k.tracking()
+        for _ in range(repeats):
+            k.integration()
+            vols.append(k.download(native.BUF_VOLUME)[..., 1].astype(np.int32))
+        k.raycasting()
+        k.end_frame()
+    assert kf.status(10)["integrated"] and ref.status(10)["integrated"]
+    once, also_once, twice, thrice = vols
+    assert np.array_equal(once, also_once)
+    touched = twice - once
+    assert touched.min() == 0 and touched.max() == 1 and touched.sum() > 1000
+    assert np.array_equal(thrice - twice, touched)
+    kf.close()
+    ref.close()
