@@ -213,6 +213,18 @@ int kfh_k_update_pose(float *d_pose16, double *d_x6, int *d_converged, const flo
 int kfh_k_integrate(void *d_volume, const int32_t res[3], const float dim[3], int z0, int z1,
                     const float *d_depth, int w, int h, const float invTrack[16], const float K[16],
                     float mu, float maxweight, void *stream);
+/* kfh_k_integrate for callers that cannot allocate (code under HIP graph capture, tight serving loops, harnesses
+ * that forbid hipMalloc).  It has no counterpart in the reference.  Same arguments and the same voxels as
+ * kfh_k_integrate, but the work list of the two launches lives in a fixed 2 MiB + 512 B array in device memory
+ * (one copy per device, kept until the process ends) instead of a per-call hipMalloc, the pose travels as a kernel
+ * argument instead of a host-to-device copy, and the call returns without waiting: everything is queued on
+ * `stream`.  Volumes whose work list exceeds the array (more than 524288 boxes of 64 x 4 x {16, 32, 64} voxels:
+ * beyond 2048^3) are refused with KFH_ERR_INVALID_ARG.  All calls on one device share that device's array: calls
+ * that overlap on one device (different streams or threads) race; calls on one stream are safe back to back.
+ * The first call on a device looks the array's address up (hipGetSymbolAddress); make it outside a capture. */
+int kfh_k_integrate_noalloc(void *d_volume, const int32_t res[3], const float dim[3], int z0, int z1,
+                            const float *d_depth, int w, int h, const float invTrack[16], const float K[16],
+                            float mu, float maxweight, void *stream);
 /* raycastKernel */
 int kfh_k_raycast(void *d_vertex4, void *d_normal4, int w, int h, const void *d_volume,
                   const int32_t res[3], const float dim[3], const float view[16],

@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 
@@ -1100,6 +1101,73 @@ int kfh_k_integrate(void *d_volume, const int32_t res[3], const float dim[3], in
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     (void)hipFree(scratch);
     KFH_HIP(e);
+    return KFH_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// kfh_k_integrate for callers that cannot allocate.  The work list of the two integrate launches (what
+// kfh_k_integrate obtains from hipMalloc per call) lives in a fixed array in device memory; every device the
+// library runs on holds its own copy until the process ends.
+// ------------------------------------------------------------------------------------------------------
+}  // extern "C"
+
+namespace {
+constexpr size_t KFH_NOALLOC_LIST_BYTES = (size_t)2 << 20;            // 524288 boxes: up to 2048^3 voxels
+constexpr size_t KFH_NOALLOC_SCRATCH_BYTES = 512 + KFH_NOALLOC_LIST_BYTES;    // [inverse pose | box counter | box list]
+constexpr int KFH_NOALLOC_MAX_DEVICES = 64;
+}  // namespace
+
+static __device__ __align__(256) unsigned char scratch[KFH_NOALLOC_SCRATCH_BYTES];
+
+namespace {
+// Address of `scratch` on the current device.  In host code the array's name is only a handle: the address a
+// kernel can use comes from hipGetSymbolAddress, asked once per device with that device current.
+int noalloc_scratch(char **out) {
+    static std::mutex lock;
+    static char *address[KFH_NOALLOC_MAX_DEVICES] = {};
+    int device = -1;
+    KFH_HIP(hipGetDevice(&device));
+    if (device < 0 || device >= KFH_NOALLOC_MAX_DEVICES)
+        return fail(KFH_ERR_STATE, "device index %d is beyond the %d devices this entry point keeps scratch for", device,
+                    KFH_NOALLOC_MAX_DEVICES);
+    std::lock_guard<std::mutex> guard(lock);
+    if (!address[device]) {
+        void *p = nullptr;
+        KFH_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+        if (!p) return fail(KFH_ERR_HIP, "hipGetSymbolAddress returned a null address for the scratch array");
+        address[device] = static_cast<char *>(p);
+    }
+    *out = address[device];
+    return KFH_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int kfh_k_integrate_noalloc(void *d_volume, const int32_t res[3], const float dim[3], int z0, int z1,
+                            const float *d_depth, int w, int h, const float invTrack[16], const float K[16], float mu,
+                            float maxweight, void *stream) {
+    KFH_REQUIRE(d_volume && res && dim && d_depth && invTrack && K, "NULL argument");
+    KFH_REQUIRE(res[0] > 0 && res[1] > 0 && res[2] > 0 && 0 <= z0 && z0 < z1 && z1 <= res[2], "bad volume range");
+    KFH_REQUIRE(w > 0 && h > 0 && mu > 0.f, "bad argument");
+    const size_t list_bytes = integrate_box_list_bytes(res, z1);
+    if (list_bytes > KFH_NOALLOC_LIST_BYTES)
+        return fail(KFH_ERR_INVALID_ARG,
+                    "a %dx%dx%d volume up to plane %d needs a work list of %zu bytes; kfh_k_integrate_noalloc holds %zu "
+                    "(use kfh_k_integrate, which allocates per call)", res[0], res[1], res[2], z1, list_bytes,
+                    KFH_NOALLOC_LIST_BYTES);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    char *ptr = nullptr;
+    if (int rc = noalloc_scratch(&ptr)) return rc;
+    Mat4 *d_inv = reinterpret_cast<Mat4 *>(ptr);
+    unsigned *d_count = reinterpret_cast<unsigned *>(ptr + 256);
+    Mat4 inv, Km;
+    std::memcpy(inv.m, invTrack, sizeof(inv.m));
+    std::memcpy(Km.m, K, sizeof(Km.m));
+    // the matrix travels as a kernel argument and the same launch empties the list left by the previous call
+    KFH_HIP(launch_store_mat4(d_inv, inv, d_count, s));
+    KFH_HIP(launch_integrate(static_cast<short2 *>(d_volume), res, dim, z0, z1, d_depth, w, h, d_inv, Km, mu, maxweight,
+                             nullptr, reinterpret_cast<unsigned *>(ptr + 512), d_count, nullptr, nullptr, s));
     return KFH_OK;
 }
 

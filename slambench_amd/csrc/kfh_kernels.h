@@ -222,6 +222,8 @@ hipError_t launch_render_track(uchar4 *out, const kfh_track_data *data, const si
                                int h, hipStream_t s);
 hipError_t launch_render_shade(uchar4 *out, const float4 *vertex, const float4 *normal, int npix,
                                const float light[3], const float ambient[3], hipStream_t s);
+// a matrix handed over by value (no host-to-device copy) and, optionally, one counter set to zero
+hipError_t launch_store_mat4(Mat4 *d_out, const Mat4 &m, unsigned *d_zeroed, hipStream_t s);
 // view = pose * inverse camera matrix, written to device memory for launch_raycast
 hipError_t launch_view_from_pose(Mat4 *d_view, const Mat4 &pose, const float k[4], hipStream_t s);
 

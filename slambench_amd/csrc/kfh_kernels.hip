@@ -2768,6 +2768,16 @@ hipError_t launch_render_shade(uchar4 *out, const float4 *vertex, const float4 *
     return hipGetLastError();
 }
 
+__global__ void k_store_mat4(Mat4 *out, Mat4 m, unsigned *zeroed) {
+    if (threadIdx.x < 16) out->m[threadIdx.x] = m.m[threadIdx.x];
+    if (threadIdx.x == 16 && zeroed) *zeroed = 0u;
+}
+
+hipError_t launch_store_mat4(Mat4 *d_out, const Mat4 &m, unsigned *d_zeroed, hipStream_t s) {
+    hipLaunchKernelGGL(k_store_mat4, dim3(1), dim3(64), 0, s, d_out, m, d_zeroed);
+    return hipGetLastError();
+}
+
 hipError_t launch_view_from_pose(Mat4 *d_view, const Mat4 &pose, const float k[4], hipStream_t s) {
     hipLaunchKernelGGL(k_view_from_pose, dim3(1), dim3(64), 0, s, d_view, pose, k[0], k[1], k[2], k[3]);
     return hipGetLastError();

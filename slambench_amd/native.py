@@ -29,7 +29,7 @@ EXPORTED_SYMBOLS = (
     "kfh_render", "kfh_render_device", "kfh_enable_track_render",
     "kfh_k_render_depth", "kfh_k_render_track", "kfh_k_render_volume",
     "kfh_k_preprocess", "kfh_k_bilateral", "kfh_k_half_sample", "kfh_k_vertex_normal",
-    "kfh_k_track_reduce", "kfh_k_update_pose", "kfh_k_integrate", "kfh_k_raycast",
+    "kfh_k_track_reduce", "kfh_k_update_pose", "kfh_k_integrate", "kfh_k_integrate_noalloc", "kfh_k_raycast",
 )
 
 
@@ -85,6 +85,7 @@ def lib():
         "kfh_k_track_reduce": [vp, vp, i32, vp, vp, vp, i32, i32, vp, vp, i32, i32, vp, vp, f32, f32, vp],
         "kfh_k_update_pose": [vp, vp, vp, vp, f32, vp],
         "kfh_k_integrate": [vp, vp, vp, i32, i32, vp, i32, i32, vp, vp, f32, f32, vp],
+        "kfh_k_integrate_noalloc": [vp, vp, vp, i32, i32, vp, i32, i32, vp, vp, f32, f32, vp],
         "kfh_k_raycast": [vp, vp, i32, i32, vp, vp, vp, vp, f32, f32, f32, f32, vp],
         "kfh_render": [vp, i32, vp, vp, C.c_size_t], "kfh_render_device": [vp, i32, vp, vp],
         "kfh_enable_track_render": [vp, i32],
