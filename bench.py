@@ -67,6 +67,9 @@ def parse_args():
     ap.add_argument("--icp", choices=["replicated", "allreduce"], default="replicated",
                     help="--mode zslab: every rank tracks the whole image (no collective), or every rank tracks its "
                          "rows and the 32 ICP sums are all-reduced per iteration")
+    ap.add_argument("--force-exchange", action="store_true",
+                    help="--mode zslab on ONE rank: still take the exchange path (slab march, all-gather, composite, "
+                         "all-reduce) through a single-rank RCCL group, to time the collectives' fixed cost")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "integrate_traffic.json"),
                     help="HBM bytes per integrate launch from the committed rocprofv3 PMC passes")
     return ap.parse_args()
@@ -105,6 +108,21 @@ def cpu_baseline(cfg, depth, frames, threads):
     dt = time.perf_counter() - t0
     ref.close()
     return frames / dt, np.stack(poses), phases / frames, threads
+
+
+class stdout_to_stderr:
+    """RCCL prints a version banner on stdout when its first communicator comes up; the benchmark's stdout must hold
+    the one JSON line only, so the file descriptor is pointed at stderr while the process group starts."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
 
 
 def spawn_ranks(a):
@@ -184,15 +202,21 @@ def main():
     if backend == "auto":
         backend = "nccl" if world <= n_devices else "gloo"     # RCCL wants one device per rank
     ranks_seen = 1
-    if world > 1:
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", device_index))
-        else:
-            dist.init_process_group(backend)
-        one = torch.ones(1, dtype=torch.int64, device="cuda" if backend == "nccl" else "cpu")
-        dist.all_reduce(one)                   # the ranks count themselves
-        ranks_seen = int(one.item())
-    zslab = a.mode == "zslab" and world > 1
+    solo_exchange = a.mode == "zslab" and world == 1 and a.force_exchange
+    if solo_exchange:
+        with socket.socket() as sock:
+            sock.bind(("127.0.0.1", 0))
+            port = sock.getsockname()[1]
+    if world > 1 or solo_exchange:
+        with stdout_to_stderr():
+            kw = {"device_id": torch.device("cuda", device_index)} if backend == "nccl" else {}
+            if solo_exchange:
+                kw.update(init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1)
+            dist.init_process_group(backend, **kw)
+            one = torch.ones(1, dtype=torch.int64, device="cuda" if backend == "nccl" else "cpu")
+            dist.all_reduce(one)                   # the ranks count themselves (and the communicator comes up)
+            ranks_seen = int(one.item())
+    zslab = a.mode == "zslab" and (world > 1 or solo_exchange)
 
     V = a.volume
     cfg = KFusionConfig(input_size=(640, 480), intrinsics=TUM_FR1_DEPTH_INTRINSICS, compute_size_ratio=a.csr,
@@ -210,7 +234,7 @@ def main():
 
     if zslab:
         from slambench_amd.sharded import SlabKFusion
-        sharded = SlabKFusion(cfg, rank, world, dist, torch, icp=a.icp)
+        sharded = SlabKFusion(cfg, rank, world, dist, torch, icp=a.icp, force_exchange=solo_exchange)
         kf = sharded.kf
         step = sharded.process_frame
     else:
@@ -417,7 +441,7 @@ def main():
     kf.close()
     for kq, _, _ in extra:
         kq.close()
-    if world > 1:
+    if world > 1 or solo_exchange:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:

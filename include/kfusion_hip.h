@@ -105,9 +105,12 @@ enum kfh_buffer {
     KFH_BUF_MODEL_NORMAL = 5,  /* float4[h][w]                                          */
     KFH_BUF_VOLUME = 6,        /* short2[slab_z1-slab_z0][Y][X]                         */
     KFH_BUF_RAY_T = 7,         /* float[h][w]            hit distance of the last raycast */
-    KFH_BUF_BRICK_MARKS = 8    /* uint8[Z/8][Y/8][X/8]   1: no voxel of the 8^3 brick (and one voxel past it per axis) has
+    KFH_BUF_BRICK_MARKS = 8,   /* uint8[Z/8][Y/8][X/8]   1: no voxel of the 8^3 brick (and one voxel past it per axis) has
                                   been below 26300/32766 since the last reset; the raycast skips such bricks with its
                                   coarse step.  Unsharded contexts only. */
+    KFH_BUF_MODEL_TN = 9       /* float4[h][w]           the raycast output as tracking reads it: {hit distance t along the
+                                  pixel's ray (0 = miss), normal}; the model vertex is origin + direction * t of the
+                                  raycast pose.  After kfh_raycast_slab: this device's slab segment. */
 };
 
 /* image identifiers for kfh_render: the three pictures of the kfusion plugin's sb_update_outputs */
@@ -174,15 +177,24 @@ int kfh_render_device(kfh_context *ctx, int image, const float view_pose[16], ui
  * executed iteration) after this call with enabled != 0; codes are zero ("unknown" colour) until tracking runs. */
 int kfh_enable_track_render(kfh_context *ctx, int enabled);
 
-/* ---- z-slab sharding across devices (one context per device) ---- */
-/* March only this context's slab; writes hit distance t (0 = miss), vertex and normal of the nearest
- * zero crossing inside the slab into the context's model maps (KFH_BUF_RAY_T / MODEL_*). */
+/* ---- z-slab sharding across devices (one context per device); no counterpart in the reference ---- */
+/* March only this context's slab; writes, per pixel, the hit distance t of the nearest zero crossing inside the
+ * slab (0 = none) and its normal into the packed model map (KFH_BUF_MODEL_TN).  16 bytes per pixel are all that
+ * has to be exchanged: the vertex is a function of the pixel and t. */
 int kfh_raycast_slab(kfh_context *ctx);
 /* Keep, per pixel, the candidate with the smallest positive t among n_parts gathered slab results.
- * d_t: float[n_parts][h][w], d_vertex / d_normal: float4[n_parts][h][w]; the winners are written into the
- * context's model maps. */
-int kfh_composite_slabs(kfh_context *ctx, const float *d_t, const void *d_vertex, const void *d_normal,
-                        int n_parts);
+ * d_tn_parts: float4[n_parts][h][w] in the layout of KFH_BUF_MODEL_TN; the winners become the context's model map. */
+int kfh_composite_slabs(kfh_context *ctx, const void *d_tn_parts, int n_parts);
+/* Kfusion::tracking with the pixels of every pyramid level split by rows over share_count devices that all hold the
+ * same model map and depth frame (what z-slab ranks do).  This context evaluates share `share`.  After every
+ * iteration launch the library folds this device's partial sums into one row of 32 floats (reduceKernel layout) and
+ * calls allreduce(user, d_sums32, stream): the callback must queue, in stream order on `stream`, an in-place SUM of
+ * those 32 floats over all shares (ncclAllReduce on that stream, or wait + host exchange + copy back) and return 0.
+ * It is called once per configured ICP iteration (19 with the default pyramid), from the calling thread.  Every
+ * device then solves the same 6x6 system.  allreduce == NULL is only allowed with share_count == 1 and is
+ * kfh_track; a single share with a callback still calls it (an identity then). */
+typedef int (*kfh_allreduce_fn)(void *user, float *d_sums32, void *stream);
+int kfh_track_rows(kfh_context *ctx, int share, int share_count, kfh_allreduce_fn allreduce, void *user);
 
 /* ---- stateless kernels on caller-owned device memory (used by the parity tests) ---- */
 /* mm2metersKernel (+ bilateralFilterKernel when d_filtered != NULL) */

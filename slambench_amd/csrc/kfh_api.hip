@@ -106,6 +106,8 @@ struct kfh_context {
     int in_maps_version[3] = {-1, -1, -1}; // pyramid version the input vertex / normal maps were built from
     short2 *d_volume = nullptr;
     size_t volume_voxels = 0;
+    float *d_reduced = nullptr;            // row-sharded tracking: two alternating rows of 32 sums (this device's share,
+                                           //   then all devices' after the caller's all-reduce); allocated on first use
     float *d_partials = nullptr;           // two alternating buffers of per-block partial rows
     size_t partials_stride = 0;            // floats per buffer
     Ctrl *d_ctrl = nullptr;
@@ -179,7 +181,7 @@ void free_all(kfh_context *c) {
                     c->set_scaled[1][2],
                     c->d_in_vertex[0], c->d_in_vertex[1], c->d_in_vertex[2], c->d_in_normal[0],
                     c->d_in_normal[1], c->d_in_normal[2], c->d_vertex, c->d_normal, c->d_ray_t, c->d_volume, c->d_ref_tn, c->d_ray_tasks, c->d_integrate_boxes, c->d_bricks,
-                    c->d_partials, c->d_ctrl, c->d_status, c->d_stamps, c->d_track_codes, c->d_render_vertex,
+                    c->d_partials, c->d_reduced, c->d_ctrl, c->d_status, c->d_stamps, c->d_track_codes, c->d_render_vertex,
                     c->d_render_normal, c->d_render_rgba, c->d_render_state};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
@@ -464,9 +466,11 @@ int kfh_preprocess(kfh_context *c) {
     return KFH_OK;
 }
 
-int kfh_track(kfh_context *c) {
-    KFH_REQUIRE(c != nullptr, "context is NULL");
-    DeviceScope on_device(c->device);
+// Kfusion::tracking.  share_count == 1: the whole image on this device, one launch per iteration.  Otherwise this
+// device evaluates tile rows [share * T / share_count, (share + 1) * T / share_count) of every level's T tile rows;
+// after every iteration launch its partial rows are folded into one row of 32 sums and `allreduce` must queue, in
+// stream order, an in-place sum of that row over all devices, which the next launch (or the finish) then solves.
+static int track_impl(kfh_context *c, int share, int share_count, kfh_allreduce_fn allreduce, void *user) {
     if (int rc = flush_tail(c)) return rc;
     KFH_HIP(ensure_pre_done(c));
     int total_iterations = 0;
@@ -489,7 +493,10 @@ int kfh_track(kfh_context *c) {
         a.result_out = c->d_track_codes;
         a.result_stride = c->w;
         a.max_blocks = c->compute_units;
+        const bool sharded = allreduce != nullptr;      // a single share with a callback still takes the exchange path
+        a.rows_reduced = sharded ? 1 : 0;
         int seq = 0, rows = 0;
+        const float *pending = nullptr;      // sharded: the all-reduced row the next launch solves
         for (int level = 2; level >= 0; --level) {
             a.level = level;
             a.in_depth = c->d_scaled[level];
@@ -497,21 +504,61 @@ int kfh_track(kfh_context *c) {
             a.iw = c->w >> level;
             a.ih = c->h >> level;
             track_shape(a.iw, a.ih, c->compute_units, &a.pw, &a.ppt);
+            const int tiles_x = (a.iw + KFH_TRACK_TILE_W - 1) / KFH_TRACK_TILE_W;
+            const int tile_rows = track_blocks(a.iw, a.ih, a.pw, a.ppt) / tiles_x;
+            if (sharded) {
+                if (tile_rows < share_count)
+                    return fail(KFH_ERR_INVALID_ARG, "pyramid level %d has %d tile rows, fewer than the %d shares", level,
+                                tile_rows, share_count);
+                const int r0 = (int)((long long)share * tile_rows / share_count);
+                const int r1 = (int)((long long)(share + 1) * tile_rows / share_count);
+                a.block0 = r0 * tiles_x;
+                a.block_count = (r1 - r0) * tiles_x;
+            }
             for (int i = 0; i < c->cfg.pyramid[level]; ++i, ++seq) {
                 a.seq = seq;
                 a.last_iter = (i == c->cfg.pyramid[level] - 1) ? 1 : 0;
-                a.partials_in = c->d_partials + (size_t)(seq & 1) * c->partials_stride;
+                a.partials_in = sharded ? (pending ? pending : c->d_reduced) : c->d_partials + (size_t)(seq & 1) * c->partials_stride;
                 a.partials_out = c->d_partials + (size_t)((seq + 1) & 1) * c->partials_stride;
                 a.pending_rows = rows;
                 KFH_HIP(launch_icp_iteration(a, c->stream));
-                rows = track_blocks(a.iw, a.ih, a.pw, a.ppt);
+                if (sharded) {
+                    float *row = c->d_reduced + (size_t)((seq + 1) & 1) * 64;
+                    KFH_HIP(launch_sum_partials(row, a.partials_out, a.block_count, c->stream));
+                    if (int rc = allreduce(user, row, c->stream))
+                        return fail(KFH_ERR_STATE, "the all-reduce callback of kfh_track_rows failed with code %d", rc);
+                    pending = row;
+                    rows = 1;
+                } else {
+                    rows = track_blocks(a.iw, a.ih, a.pw, a.ppt);
+                }
             }
         }
-        KFH_HIP(launch_icp_finish(finish_args(c, seq, rows), c->stream));
+        FinishArgs f = finish_args(c, seq, rows);
+        if (sharded) f.partials_in = pending;
+        KFH_HIP(launch_icp_finish(f, c->stream));
     }
     c->box_list_fresh = c->ray_list_fresh = true;      // both finish kernels empty the lists and set the raycast matrices
     if (timed_frame(c)) KFH_HIP(hipEventRecord(c->ev[c->frame % KFH_TIMING_RING][2], c->stream));
     return KFH_OK;
+}
+
+int kfh_track(kfh_context *c) {
+    KFH_REQUIRE(c != nullptr, "context is NULL");
+    DeviceScope on_device(c->device);
+    return track_impl(c, 0, 1, nullptr, nullptr);
+}
+
+int kfh_track_rows(kfh_context *c, int share, int share_count, kfh_allreduce_fn allreduce, void *user) {
+    KFH_REQUIRE(c != nullptr, "context is NULL");
+    KFH_REQUIRE(share_count >= 1 && share >= 0 && share < share_count, "share %d of %d is out of range", share, share_count);
+    KFH_REQUIRE(share_count == 1 || allreduce != nullptr, "more than one share needs an all-reduce callback");
+    DeviceScope on_device(c->device);
+    if (allreduce != nullptr && !c->d_reduced) {
+        KFH_HIP(dev_alloc(&c->d_reduced, (size_t)128));
+        KFH_HIP(hipMemsetAsync(c->d_reduced, 0, 128 * sizeof(float), c->stream));
+    }
+    return track_impl(c, share, share_count, allreduce, user);
 }
 
 // The per-tile depth maxima let the integration drop boxes behind the seen surface (KFH_NO_DEPTH_CULL: off).
@@ -617,7 +664,8 @@ int kfh_raycast_slab(kfh_context *c) {
     if (int rc = flush_tail(c)) return rc;
     if (c->frame > 2) {
         if (int rc = prepare_ray_list(c)) return rc;
-        KFH_HIP(launch_raycast(c->d_vertex, c->d_normal, c->d_ray_t, nullptr, c->w, c->h, c->d_volume,
+        c->model_maps_stale = true;
+        KFH_HIP(launch_raycast(nullptr, nullptr, nullptr, c->d_ref_tn, c->w, c->h, c->d_volume,
                                c->cfg.vol_res, c->cfg.vol_dim, c->cfg.slab_z0, c->cfg.slab_z1, &c->d_ctrl->view, NEAR_PLANE,
                                FAR_PLANE, raycast_step(c->cfg), 0.75f * c->cfg.mu, c->d_ray_tasks,
                                &c->d_ctrl->ray_task_count, nullptr, c->stream));
@@ -625,14 +673,14 @@ int kfh_raycast_slab(kfh_context *c) {
     return KFH_OK;
 }
 
-int kfh_composite_slabs(kfh_context *c, const float *d_t, const void *d_vertex, const void *d_normal, int n_parts) {
-    KFH_REQUIRE(c != nullptr && d_t && d_vertex && d_normal, "NULL argument");
+int kfh_composite_slabs(kfh_context *c, const void *d_tn_parts, int n_parts) {
+    KFH_REQUIRE(c != nullptr && d_tn_parts != nullptr, "NULL argument");
     DeviceScope on_device(c->device);
     if (int rc = flush_tail(c)) return rc;
     KFH_REQUIRE(n_parts >= 1 && n_parts <= 64, "n_parts=%d out of range", n_parts);
     if (c->frame > 2) {
-        KFH_HIP(launch_composite(c->d_vertex, c->d_normal, c->d_ray_t, c->d_ref_tn, d_t, static_cast<const float4 *>(d_vertex),
-                                 static_cast<const float4 *>(d_normal), n_parts, c->w * c->h, c->stream));
+        c->model_maps_stale = true;
+        KFH_HIP(launch_composite(c->d_ref_tn, static_cast<const float4 *>(d_tn_parts), n_parts, c->w * c->h, c->stream));
     }
     return KFH_OK;
 }
@@ -831,6 +879,7 @@ int kfh_device_ptr(kfh_context *c, int buffer, int level, void **d_ptr, size_t *
             if (buffer == KFH_BUF_RAY_T) { *d_ptr = c->d_ray_t; *bytes = npix * sizeof(float); }
             else { *d_ptr = buffer == KFH_BUF_MODEL_VERTEX ? c->d_vertex : c->d_normal; *bytes = npix * sizeof(float4); }
             break;
+        case KFH_BUF_MODEL_TN: *d_ptr = c->d_ref_tn; *bytes = npix * sizeof(float4); break;
         case KFH_BUF_VOLUME: *d_ptr = c->d_volume; *bytes = c->volume_voxels * sizeof(short2); break;
         case KFH_BUF_BRICK_MARKS:
             if (!c->d_bricks) return fail(KFH_ERR_STATE, "this context keeps no brick marks (sharded volume)");

@@ -114,6 +114,10 @@ struct IcpIterArgs {
     signed char *result_out;    // per-pixel result code of trackKernel (1, -1 .. -5) for the tracking render, may be null
     int result_stride;
     unsigned long long *stamps; // diagnostic time stamps [launch][block][slot], may be null
+    // A device that evaluates only a share of the image (row-sharded tracking across devices): first tile and
+    // number of tiles of its share (0 = all from block0 on), and whether a launch between two iterations folds
+    // the partial rows of all devices into ONE row (then the next launch finds pending_nblocks == 1).
+    int block0, block_count, rows_reduced;
 };
 
 struct FinishArgs {
@@ -204,9 +208,7 @@ hipError_t launch_raycast_part(float4 *vertex, float4 *normal, float *ray_t, flo
                                const PreprocessLaunch *with_preprocess, hipStream_t s);
 hipError_t launch_model_maps(float4 *vertex, float4 *normal, float *ray_t, const float4 *ref_tn, const Mat4 *view,
                              int w, int h, hipStream_t s);
-hipError_t launch_composite(float4 *vertex, float4 *normal, float *ray_t, float4 *ref_tn, const float *t_parts,
-                            const float4 *v_parts, const float4 *n_parts, int n_parts_count, int npix,
-                            hipStream_t s);
+hipError_t launch_composite(float4 *ref_tn, const float4 *tn_parts, int n_parts_count, int npix, hipStream_t s);
 // diagnostics: per-wavefront records of every following raycast launch go to d_buffer (null: off)
 void set_raycast_debug(unsigned long long *d_buffer);
 void set_integrate_debug(unsigned long long *d_buffer);

@@ -931,7 +931,8 @@ __global__ __launch_bounds__(64 * (1 + PW)) void k_icp_iteration(const float *__
 
     const int tile_h = PW * PPT;
     const int tiles_x = (a.iw + KFH_TRACK_TILE_W - 1) / KFH_TRACK_TILE_W;
-    const int tile_y = blockIdx.x / tiles_x, tile_x = blockIdx.x - tile_y * tiles_x;
+    const int tile = (int)blockIdx.x + a.block0;      // block0 != 0: this device evaluates a share of the image's tiles
+    const int tile_y = tile / tiles_x, tile_x = tile - tile_y * tiles_x;
     const int x_raw = tile_x * KFH_TRACK_TILE_W + lane;
     const int y0 = tile_y * tile_h + max(pw, 0) * PPT;
     const int x = min(x_raw, a.iw - 1);               // clamped: every load stays inside the image
@@ -1202,7 +1203,9 @@ __global__ __launch_bounds__(64 * (1 + PW)) void k_icp_iteration(const float *__
             for (int w = 1; w < PW; ++w) t += sh.part[w][lane];
             a.partials_out[blockIdx.x * 32 + lane] = t;
         }
-        if (blockIdx.x == 0) icp_store_state(out, sh, gridDim.x, a.level, a.last_iter);
+        // rows_reduced: a launch between this one and the next folds the rows (and those of the other devices)
+        // into a single row
+        if (blockIdx.x == 0) icp_store_state(out, sh, a.rows_reduced ? 1 : (int)gridDim.x, a.level, a.last_iter);
     }
     KFH_STAMP(6, 0);
     if (KFH_STAMPS_COMPILED && a.stamps != nullptr && threadIdx.x == 0 && blockIdx.x < KFH_STAMP_BLOCKS && a.seq < KFH_STAMP_LAUNCHES)
@@ -1246,7 +1249,10 @@ hipError_t launch_icp_iteration(const IcpIterArgs &a_in, hipStream_t s) {
         const Mat4 ik = inverse_camera_matrix(a.k[0], a.k[1], a.k[2], a.k[3]);
         a.ik[0] = ik.m[0]; a.ik[1] = ik.m[2]; a.ik[2] = ik.m[5]; a.ik[3] = ik.m[6];
     }
-    const int nb = track_blocks(a.iw, a.ih, a.pw, a.ppt);
+    const int all = track_blocks(a.iw, a.ih, a.pw, a.ppt);
+    if (a.block0 < 0 || a.block_count < 0 || a.block0 + a.block_count > all) return hipErrorInvalidValue;
+    const int nb = a.block_count > 0 ? a.block_count : all - a.block0;      // block_count == 0: all tiles from block0 on
+    if (nb <= 0) return hipErrorInvalidValue;
     bool ok = false;
     ok = packed ? launch_icp_shape<true>(a, nb, s) : launch_icp_shape<false>(a, nb, s);
     if (!ok) return hipErrorInvalidValue;
@@ -1415,6 +1421,7 @@ hipError_t launch_track_reduce(Ctrl *scratch_ctrl, float *partials, float *sums,
     a.track_out = track_out; a.track_stride = track_stride;
     a.result_out = nullptr; a.result_stride = 0;
     a.stamps = nullptr;
+    a.block0 = 0; a.block_count = 0; a.rows_reduced = 0;
     hipError_t e = launch_icp_iteration(a, s);
     if (e != hipSuccess) return e;
     return launch_sum_partials(sums, partials, track_blocks(iw, ih, a.pw, a.ppt), s);
@@ -2593,35 +2600,24 @@ hipError_t launch_raycast_part(float4 *vertex, float4 *normal, float *ray_t, flo
 #undef KFH_RAYCAST_ARGS
 }
 
-// Per pixel, keep the slab candidate with the smallest positive hit distance.
-__global__ __launch_bounds__(256) void k_composite(float4 *__restrict__ vertex, float4 *__restrict__ normal,
-                                                   float *__restrict__ ray_t, float4 *__restrict__ ref_tn,
-                                                   const float *__restrict__ t_parts,
-                                                   const float4 *__restrict__ v_parts,
-                                                   const float4 *__restrict__ n_parts, int n, int npix) {
+// Per pixel, keep the slab candidate with the smallest positive hit distance.  Candidates and result are packed
+// maps {hit distance (0 = miss), normal}: the vertex of a candidate is origin + direction * t of the pixel's ray,
+// the same for every slab, so the distance and the normal are all that has to travel between devices.
+__global__ __launch_bounds__(256) void k_composite(float4 *__restrict__ ref_tn, const float4 *__restrict__ tn_parts,
+                                                   int n, int npix) {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= npix) return;
-    float best = 0.f;
-    int arg = -1;
+    float4 best = make_float4(0.f, KFH_INVALID, 0.f, 0.f);
+    bool have = false;
     for (int i = 0; i < n; ++i) {
-        const float t = t_parts[(size_t)i * npix + p];
-        if (t > 0.f && (arg < 0 || t < best)) { best = t; arg = i; }
+        const float4 c = tn_parts[(size_t)i * npix + p];
+        if (c.x > 0.f && (!have || c.x < best.x)) { best = c; have = true; }
     }
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f), nrm = make_float4(KFH_INVALID, 0.f, 0.f, 0.f);
-    if (arg >= 0) {
-        v = v_parts[(size_t)arg * npix + p];
-        nrm = n_parts[(size_t)arg * npix + p];
-    }
-    vertex[p] = v;
-    normal[p] = nrm;
-    if (ref_tn) ref_tn[p] = make_float4(best, nrm.x, nrm.y, nrm.z);
-    if (ray_t) ray_t[p] = best;
+    ref_tn[p] = best;
 }
 
-hipError_t launch_composite(float4 *vertex, float4 *normal, float *ray_t, float4 *ref_tn, const float *t_parts,
-                            const float4 *v_parts, const float4 *n_parts, int n, int npix, hipStream_t s) {
-    hipLaunchKernelGGL(k_composite, dim3((npix + 255) / 256), dim3(256), 0, s, vertex, normal, ray_t, ref_tn, t_parts,
-                       v_parts, n_parts, n, npix);
+hipError_t launch_composite(float4 *ref_tn, const float4 *tn_parts, int n, int npix, hipStream_t s) {
+    hipLaunchKernelGGL(k_composite, dim3((npix + 255) / 256), dim3(256), 0, s, ref_tn, tn_parts, n, npix);
     return hipGetLastError();
 }
 

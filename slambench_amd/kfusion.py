@@ -148,7 +148,7 @@ class KFusion:
         if buffer in (native.BUF_FLOAT_DEPTH, native.BUF_SCALED_DEPTH, native.BUF_RAY_T):
             out = np.empty((h, w), np.float32)
         elif buffer in (native.BUF_INPUT_VERTEX, native.BUF_INPUT_NORMAL, native.BUF_MODEL_VERTEX,
-                        native.BUF_MODEL_NORMAL):
+                        native.BUF_MODEL_NORMAL, native.BUF_MODEL_TN):
             out = np.empty((h, w, 4), np.float32)
         elif buffer == native.BUF_VOLUME:
             rx, ry, _ = self.cfg.volume_resolution

@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libkfusion_hip_core.so")
 
 KFH_OK = 0
 BUF_FLOAT_DEPTH, BUF_SCALED_DEPTH, BUF_INPUT_VERTEX, BUF_INPUT_NORMAL = 0, 1, 2, 3
-BUF_MODEL_VERTEX, BUF_MODEL_NORMAL, BUF_VOLUME, BUF_RAY_T, BUF_BRICK_MARKS = 4, 5, 6, 7, 8
+BUF_MODEL_VERTEX, BUF_MODEL_NORMAL, BUF_VOLUME, BUF_RAY_T, BUF_BRICK_MARKS, BUF_MODEL_TN = 4, 5, 6, 7, 8, 9
 RENDER_DEPTH, RENDER_TRACK, RENDER_VOLUME = 0, 1, 2
 
 # every symbol include/kfusion_hip.h declares
@@ -25,12 +25,16 @@ EXPORTED_SYMBOLS = (
     "kfh_sync",
     "kfh_get_pose", "kfh_set_pose", "kfh_get_status", "kfh_frame_index", "kfh_integrate_totals", "kfh_compute_size",
     "kfh_download", "kfh_device_ptr", "kfh_stream", "kfh_set_timing", "kfh_phase_ms", "kfh_phase_ms_frame",
-    "kfh_raycast_slab", "kfh_composite_slabs",
+    "kfh_raycast_slab", "kfh_composite_slabs", "kfh_track_rows",
     "kfh_render", "kfh_render_device", "kfh_enable_track_render",
     "kfh_k_render_depth", "kfh_k_render_track", "kfh_k_render_volume",
     "kfh_k_preprocess", "kfh_k_bilateral", "kfh_k_half_sample", "kfh_k_vertex_normal",
     "kfh_k_track_reduce", "kfh_k_update_pose", "kfh_k_integrate", "kfh_k_integrate_noalloc", "kfh_k_raycast",
 )
+
+
+# int (*kfh_allreduce_fn)(void *user, float *d_sums32, void *stream)
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p)
 
 
 class FrameStatus(C.Structure):
@@ -77,7 +81,8 @@ def lib():
         "kfh_device_ptr": [vp, i32, i32, C.POINTER(vp), C.POINTER(C.c_size_t)],
         "kfh_stream": [vp, C.POINTER(vp)],
         "kfh_set_timing": [vp, i32], "kfh_phase_ms": [vp, vp], "kfh_phase_ms_frame": [vp, i32, vp],
-        "kfh_raycast_slab": [vp], "kfh_composite_slabs": [vp, vp, vp, vp, i32],
+        "kfh_raycast_slab": [vp], "kfh_composite_slabs": [vp, vp, i32],
+        "kfh_track_rows": [vp, i32, i32, ALLREDUCE_FN, vp],
         "kfh_k_preprocess": [vp, vp, i32, i32, vp, i32, i32, f32, vp],
         "kfh_k_bilateral": [vp, vp, i32, i32, vp],
         "kfh_k_half_sample": [vp, vp, i32, i32, f32, vp],

@@ -3,9 +3,11 @@
 Rank g owns the planes z in [g*Z/N, (g+1)*Z/N) of the short2 volume, plus two halo planes per side that it
 integrates redundantly, so integration needs no exchange at all.  Every rank preprocesses the (broadcast) depth
 frame and runs the full ICP on its own copy of the model maps — the 32-float ICP sums are therefore identical
-on all ranks without an all-reduce.  The only exchange step of a frame is the raycast: each rank marches the
-part of every ray that lies inside its slab, the per-slab results (hit distance, vertex, normal: 36 bytes per
-pixel) are all-gathered, and every rank keeps the nearest hit per pixel (kfh_composite_slabs).
+on all ranks without an all-reduce (icp="allreduce" splits the pixels by rows instead and all-reduces the sums
+after every iteration: kfh_track_rows).  The only other exchange step of a frame is the raycast: each rank marches
+the part of every ray that lies inside its slab, the per-slab results (hit distance and normal: 16 bytes per pixel;
+the vertex is a function of the pixel and the distance) are all-gathered in one collective, and every rank keeps the
+nearest hit per pixel (kfh_composite_slabs).
 
 The reference has no multi-device path at all (no NCCL/MPI anywhere in its tree); this module is the new
 component the volume-size axis of the reference's design space (volume-resolution) needs on an 8-GPU node.
@@ -35,89 +37,121 @@ def slab_bounds(z_res, world_size, rank):
     return z0, z0 + base + (1 if rank < extra else 0)
 
 
-def composite_numpy(t_parts, v_parts, n_parts):
-    """Host restatement of kfh_composite_slabs: per pixel, the candidate with the smallest positive t."""
-    t = np.asarray(t_parts, np.float32)
+def composite_numpy(tn_parts):
+    """Host restatement of kfh_composite_slabs on packed maps [parts][h][w][4] = {t, normal}: per pixel, the
+    candidate with the smallest positive t; a pixel no slab hit gets {0, (-2, 0, 0)}."""
+    tn = np.asarray(tn_parts, np.float32)
+    t = tn[..., 0]
     masked = np.where(t > 0, t, np.inf)
     arg = masked.argmin(axis=0)
     hit = np.isfinite(masked.min(axis=0))
     idx = np.indices(arg.shape)
-    v = np.asarray(v_parts)[(arg,) + tuple(idx)]
-    n = np.asarray(n_parts)[(arg,) + tuple(idx)]
-    v = np.where(hit[..., None], v, 0.0).astype(np.float32)
-    miss_normal = np.zeros(4, np.float32)
-    miss_normal[0] = -2.0
-    n = np.where(hit[..., None], n, miss_normal).astype(np.float32)
-    return np.where(hit, masked.min(axis=0), 0.0).astype(np.float32), v, n
+    best = tn[(arg,) + tuple(idx)]
+    miss = np.array([0.0, -2.0, 0.0, 0.0], np.float32)
+    return np.where(hit[..., None], best, miss).astype(np.float32)
 
 
 class SlabKFusion:
     """One rank's share of a sharded KinectFusion run.  `dist` is torch.distributed (already initialised)
-    or None for a single process that owns the whole volume."""
+    or None for a single process that owns the whole volume.
 
-    def __init__(self, cfg: KFusionConfig, rank=0, world_size=1, dist=None, torch=None, icp="replicated"):
+    icp="replicated": every rank tracks the whole image against its own copy of the model map (identical sums on
+    all ranks, no collective).  icp="allreduce": every rank tracks its share of the rows of each pyramid level and
+    the 32 ICP sums are all-reduced after every iteration (kfh_track_rows); 19 small collectives per frame."""
+
+    def __init__(self, cfg: KFusionConfig, rank=0, world_size=1, dist=None, torch=None, icp="replicated",
+                 force_exchange=False):
+        """force_exchange: take the exchange path (slab march, all-gather, composite, and the all-reduce when
+        icp="allreduce") even in a world of one rank: a one-GPU box can then run the device-side collectives."""
         if icp not in ("replicated", "allreduce"):
             raise ValueError("icp must be 'replicated' or 'allreduce'")
         self.rank, self.world = rank, world_size
         self.dist, self.torch = dist, torch
-        self.icp = icp if world_size > 1 else "replicated"
+        self.exchange = world_size > 1 or (force_exchange and dist is not None)
+        self.icp = icp if self.exchange else "replicated"
         z0, z1 = slab_bounds(cfg.volume_resolution[2], world_size, rank)
         self.cfg = KFusionConfig(**{**cfg.__dict__, "slab": (z0, z1) if world_size > 1 else (0, 0)})
         self.kf = KFusion(self.cfg)
         w, h = self.cfg.compute_size
         self.npix = w * h
-        self._bufs = None
+        self._gathered = None
+        self._mine = None
+        self._sums = {}
+        self.allreduce_calls = 0
+        self._device_collectives = self.exchange and dist.get_backend() == "nccl"
+        # RCCL work is ordered against torch's current stream: make the context's own stream that stream around
+        # the collectives, so that neither side has to wait for the host
+        self._stream = torch.cuda.ExternalStream(self.kf.stream()) if self._device_collectives else None
+        self._callback = native.ALLREDUCE_FN(self._allreduce_sums)      # kept alive with the object
 
     def close(self):
         self.kf.close()
 
     # -- exchange -----------------------------------------------------------------------------------------
+    def _allreduce_sums(self, user, d_sums32, stream):
+        """kfh_allreduce_fn: in-place sum of one row of 32 ICP sums over all ranks, in stream order."""
+        try:
+            torch, dist = self.torch, self.dist
+            t = self._sums.get(d_sums32)
+            if t is None:
+                t = self._sums[d_sums32] = _wrap_device_buffer(torch, d_sums32, (32,))
+            self.allreduce_calls += 1
+            if self._device_collectives:
+                with torch.cuda.stream(self._stream):
+                    dist.all_reduce(t)
+            else:                         # gloo: the row takes a round trip through host memory
+                self.kf.sync()
+                host = t.cpu()
+                dist.all_reduce(host)
+                t.copy_(host)
+                torch.cuda.synchronize()
+            return 0
+        except Exception as exc:          # an exception must not unwind through the C caller
+            self._callback_error = exc
+            return 1
+
     def _gather(self):
-        """All-gather (t, vertex, normal) of this rank's slab march; returns device pointers of the gathered
-        [world][...] arrays, kept alive in self._bufs."""
+        """All-gather the packed slab segments {t, normal} (16 bytes per pixel) of all ranks; returns the device
+        pointer of the gathered [world][h][w][4] array."""
         torch, dist = self.torch, self.dist
         kf = self.kf
         w, h = self.cfg.compute_size
-        if self._bufs is None:
-            dev = "cuda"
-            self._bufs = {
-                "t": torch.empty((self.world, h, w), dtype=torch.float32, device=dev),
-                "v": torch.empty((self.world, h, w, 4), dtype=torch.float32, device=dev),
-                "n": torch.empty((self.world, h, w, 4), dtype=torch.float32, device=dev),
-            }
-        kf.sync()        # the slab march ran on the context's stream; the collectives use torch's
-        parts = {}
-        for key, buf_id, shape in (("t", native.BUF_RAY_T, (h, w)), ("v", native.BUF_MODEL_VERTEX, (h, w, 4)),
-                                   ("n", native.BUF_MODEL_NORMAL, (h, w, 4))):
-            ptr, nbytes = kf.device_ptr(buf_id)
-            mine = _wrap_device_buffer(torch, ptr, shape)
-            if dist.get_backend() == "nccl":
-                dist.all_gather_into_tensor(self._bufs[key], mine)
-            else:                     # gloo: stage through the host (used by the CPU / single-GPU rehearsal)
-                host = mine.cpu()
-                out = [torch.empty_like(host) for _ in range(self.world)]
-                dist.all_gather(out, host)
-                self._bufs[key].copy_(torch.stack(out))
-            parts[key] = self._bufs[key]
-        torch.cuda.synchronize()
-        return parts
+        if self._gathered is None:
+            self._gathered = torch.empty((self.world, h, w, 4), dtype=torch.float32, device="cuda")
+            ptr, _ = kf.device_ptr(native.BUF_MODEL_TN)
+            self._mine = _wrap_device_buffer(torch, ptr, (h, w, 4))
+        if self._device_collectives:
+            with torch.cuda.stream(self._stream):
+                dist.all_gather_into_tensor(self._gathered, self._mine)
+        else:                             # gloo: stage through the host (CPU / single-GPU rehearsal)
+            kf.sync()
+            host = self._mine.cpu()
+            out = [torch.empty_like(host) for _ in range(self.world)]
+            dist.all_gather(out, host)
+            self._gathered.copy_(torch.stack(out))
+            torch.cuda.synchronize()
+        return self._gathered.data_ptr()
 
     # -- one frame ----------------------------------------------------------------------------------------
     def process_frame(self, depth):
         kf = self.kf
         kf.set_depth(depth)
         kf.preprocessing()
-        kf.tracking()
+        if self.icp == "allreduce":
+            self._callback_error = None
+            rc = kf._L.kfh_track_rows(kf._ctx, self.rank, self.world, self._callback, None)
+            if self._callback_error is not None:
+                raise self._callback_error
+            native.check(rc)
+        else:
+            kf.tracking()
         kf.integration()
-        if self.world == 1:
+        if not self.exchange:
             kf.raycasting()
         else:
             native.check(kf._L.kfh_raycast_slab(kf._ctx))
             if kf.frame > 2:
-                p = self._gather()
-                native.check(kf._L.kfh_composite_slabs(kf._ctx, C.c_void_p(p["t"].data_ptr()),
-                                                       C.c_void_p(p["v"].data_ptr()),
-                                                       C.c_void_p(p["n"].data_ptr()), self.world))
+                native.check(kf._L.kfh_composite_slabs(kf._ctx, C.c_void_p(self._gather()), self.world))
         kf.end_frame()
 
 

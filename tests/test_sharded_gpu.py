@@ -35,19 +35,20 @@ def test_two_slabs_reproduce_the_full_volume(torch_cuda):
             kf.integration()
             native.check(L.kfh_raycast_slab(kf._ctx))
         if i > 2:
-            t = torch.from_numpy(np.stack([kf.download(native.BUF_RAY_T) for kf in slabs])).cuda()
-            v = torch.from_numpy(np.stack([kf.download(native.BUF_MODEL_VERTEX) for kf in slabs])).cuda()
-            nm = torch.from_numpy(np.stack([kf.download(native.BUF_MODEL_NORMAL) for kf in slabs])).cuda()
+            tn = torch.from_numpy(np.stack([kf.download(native.BUF_MODEL_TN) for kf in slabs])).cuda()
             for kf in slabs:
-                native.check(L.kfh_composite_slabs(kf._ctx, C.c_void_p(t.data_ptr()), C.c_void_p(v.data_ptr()),
-                                                   C.c_void_p(nm.data_ptr()), 2))
+                native.check(L.kfh_composite_slabs(kf._ctx, C.c_void_p(tn.data_ptr()), 2))
             if i == 3:
                 # device composite == host restatement of the min-t rule
-                tc, vc, nc = composite_numpy(t.cpu().numpy(), v.cpu().numpy(), nm.cpu().numpy())
-                assert np.array_equal(slabs[0].download(native.BUF_MODEL_VERTEX), vc)
-                assert np.array_equal(slabs[0].download(native.BUF_RAY_T), tc)
+                want = composite_numpy(tn.cpu().numpy())
+                assert np.array_equal(slabs[0].download(native.BUF_MODEL_TN), want)
+                assert np.array_equal(slabs[0].download(native.BUF_RAY_T), want[..., 0])
                 got_n = slabs[1].download(native.BUF_MODEL_NORMAL)
-                assert np.array_equal(got_n[..., 0], nc[..., 0])
+                assert np.array_equal(got_n[..., :3], want[..., 1:])
+                nc = got_n
+                vc = slabs[0].download(native.BUF_MODEL_VERTEX)
+                # the vertex map is rebuilt from the hit distance: zero where nothing was hit
+                assert np.array_equal((vc[..., :3] != 0).any(-1) | (want[..., 0] == 0), np.ones(want.shape[:2], bool))
                 # first raycast: same volume, same pose -> the composited map is the single-device map except
                 # where a ray's step state restarts at the slab boundary
                 v_full = full.download(native.BUF_MODEL_VERTEX)[..., :3]

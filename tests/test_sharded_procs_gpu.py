@@ -19,11 +19,11 @@ pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-def run_ranks(tmp_path, world, frames, volume, icp):
-    port = 29700 + (os.getpid() % 200) + (7 if icp == "allreduce" else 0)
+def run_ranks(tmp_path, world, frames, volume, icp, backend="gloo"):
+    port = 29700 + (os.getpid() % 200) + (7 if icp == "allreduce" else 0) + (13 if backend == "nccl" else 0)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(HERE, "sharded_worker.py"),
-           str(tmp_path), str(frames), str(volume), icp]
+           str(tmp_path), str(frames), str(volume), icp, backend]
     env = dict(os.environ, OMP_NUM_THREADS="4", HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
@@ -45,16 +45,14 @@ def in_process_slabs(torch, frames, V):
             kf.integration()
             native.check(L.kfh_raycast_slab(kf._ctx))
         if i > 2:
-            t = torch.from_numpy(np.stack([kf.download(native.BUF_RAY_T) for kf in slabs])).cuda()
-            v = torch.from_numpy(np.stack([kf.download(native.BUF_MODEL_VERTEX) for kf in slabs])).cuda()
-            nm = torch.from_numpy(np.stack([kf.download(native.BUF_MODEL_NORMAL) for kf in slabs])).cuda()
+            tn = torch.from_numpy(np.stack([kf.download(native.BUF_MODEL_TN) for kf in slabs])).cuda()
             for kf in slabs:
-                native.check(L.kfh_composite_slabs(kf._ctx, C.c_void_p(t.data_ptr()), C.c_void_p(v.data_ptr()),
-                                                   C.c_void_p(nm.data_ptr()), 2))
+                native.check(L.kfh_composite_slabs(kf._ctx, C.c_void_p(tn.data_ptr()), 2))
         for kf in slabs:
             kf.end_frame()
     out = (slabs[0].trajectory(), np.array([slabs[0].status(f)["tracked"] for f in range(frames)]),
-           slabs[0].download(native.BUF_MODEL_VERTEX), slabs[0].download(native.BUF_MODEL_NORMAL))
+           slabs[0].download(native.BUF_MODEL_VERTEX), slabs[0].download(native.BUF_MODEL_NORMAL),
+           np.stack([slabs[0].status(f)["sums"] for f in range(frames)]))
     for kf in slabs:
         kf.close()
     return out
@@ -63,7 +61,7 @@ def in_process_slabs(torch, frames, V):
 def test_two_rank_processes_match_the_in_process_slabs(torch_cuda, tmp_path):
     frames, V = 12, 128
     ranks = run_ranks(tmp_path, 2, frames, V, "replicated")
-    traj, tracked, vertex, normal = in_process_slabs(torch_cuda, frames, V)
+    traj, tracked, vertex, normal, _ = in_process_slabs(torch_cuda, frames, V)
     assert tracked[4:].all(), "the sequence must track once the model exists"
     for r in ranks:
         # bit for bit: same kernels, same inputs, the all-gather moves bytes
@@ -71,3 +69,54 @@ def test_two_rank_processes_match_the_in_process_slabs(torch_cuda, tmp_path):
         assert np.array_equal(r["tracked"], tracked)
         assert np.array_equal(r["vertex"], vertex)
         assert np.array_equal(r["normal"], normal)
+
+
+def test_row_sharded_icp_with_allreduced_sums_matches_the_replicated_mode(torch_cuda, tmp_path):
+    """icp="allreduce": every rank tracks half of the rows of each pyramid level and the 32 sums are all-reduced
+    after every iteration.  Against the replicated mode: the counters of the last reduction are equal, its float
+    sums agree to 1e-4 of their magnitude (nineteen iterations with another summation order move a few pixels
+    across a threshold), the trajectory stays within a millimetre, and
+    both ranks hold the same bits."""
+    frames, V = 12, 128
+    ranks = run_ranks(tmp_path, 2, frames, V, "allreduce")
+    traj, tracked, vertex, normal, sums = in_process_slabs(torch_cuda, frames, V)
+    a, b = ranks
+    assert np.array_equal(a["trajectory"], b["trajectory"]) and np.array_equal(a["sums"], b["sums"])
+    assert np.array_equal(a["vertex"], b["vertex"])
+    assert np.array_equal(a["tracked"], tracked) and tracked[4:].all()
+    assert np.abs(a["trajectory"][:, :3, 3] - traj[:, :3, 3]).max() < 1e-3
+    # frame 4 is the first tracked frame: both modes start it from identical state, so its iterations see the same
+    # pixels until the poses part by rounding
+    w, h = 320, 240
+    for f in range(4, frames):
+        got, want = a["sums"][f], sums[f]
+        # every pixel of the finest level is counted exactly once over the two shares
+        assert got[28:].sum() == w * h == want[28:].sum(), (f, got[28:], want[28:])
+        # after 19 iterations whose sums were rounded in another order a pixel on a threshold may change class
+        assert np.abs(got[28:] - want[28:]).max() <= 8, (f, got[28:], want[28:])
+        scale = np.abs(want[:28]).max()
+        assert np.abs(got[:28] - want[:28]).max() <= 1e-4 * scale, f
+    assert int(a["allreduce_calls"]) == 19 * frames
+
+
+def test_device_side_collectives_on_a_single_rank_rccl_group(torch_cuda, tmp_path):
+    """The RCCL path of the exchange (all_gather_into_tensor and all_reduce on views of the library's own buffers,
+    queued against the context's stream through torch.cuda.ExternalStream, no host wait) on the one GPU of this
+    box: a world of one rank with the exchange forced.  One slab is the whole volume and one share is the whole
+    image, so the run must follow a plain single-context run (the sums are folded in another order)."""
+    frames, V = 12, 128
+    (r,) = run_ranks(tmp_path, 1, frames, V, "allreduce", backend="nccl")
+    cfg = KFusionConfig(compute_size_ratio=2, volume_resolution=(V, V, V))
+    depth, _, _ = synth.make_sequence(frames, seed=1)
+    kf = KFusion(cfg)
+    for i in range(frames):
+        kf.process_frame(depth[i])
+    traj = kf.trajectory()
+    assert np.array_equal(r["tracked"], np.array([kf.status(f)["tracked"] for f in range(frames)]))
+    assert r["tracked"][4:].all()
+    assert np.abs(r["trajectory"][:, :3, 3] - traj[:, :3, 3]).max() < 1e-4
+    # the maps of the last raycast: same volume up to the pose difference, same pixels hit
+    hit = kf.download(native.BUF_MODEL_NORMAL)[..., 0] != -2
+    assert ((r["normal"][..., 0] != -2) == hit).mean() > 0.999
+    assert int(r["allreduce_calls"]) == 19 * frames
+    kf.close()
