@@ -227,7 +227,7 @@ int kfh_k_integrate(void *d_volume, const int32_t res[3], const float dim[3], in
                     float mu, float maxweight, void *stream);
 /* kfh_k_integrate for callers that cannot allocate (code under HIP graph capture, tight serving loops, harnesses
  * that forbid hipMalloc).  It has no counterpart in the reference.  Same arguments and the same voxels as
- * kfh_k_integrate, but the work list of the two launches lives in a fixed 2 MiB + 512 B array in device memory
+ * kfh_k_integrate, but the work list of the two launches lives in a fixed 4 MiB + 512 B array in device memory
  * (one copy per device, kept until the process ends) instead of a per-call hipMalloc, the pose travels as a kernel
  * argument instead of a host-to-device copy, and the call returns without waiting: everything is queued on
  * `stream`.  Volumes whose work list exceeds the array (more than 524288 boxes of 64 x 4 x {16, 32, 64} voxels:

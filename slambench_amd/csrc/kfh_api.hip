@@ -98,7 +98,7 @@ struct kfh_context {
     float4 *d_in_normal[3] = {nullptr, nullptr, nullptr};
     float4 *d_vertex = nullptr, *d_normal = nullptr;
     unsigned char *d_bricks = nullptr;     // brick marks for the raycast (null when the volume is sharded)
-    unsigned *d_integrate_boxes = nullptr; // boxes the integrate plan launch kept for the work launch
+    void *d_integrate_boxes = nullptr;     // work items the integrate plan launch made for the work launch
     void *d_ray_tasks = nullptr;           // rays handed from the first raycast pass to the second
     float4 *d_ref_tn = nullptr;            // packed model map {hit distance, normal}: what tracking gathers
     float *d_ray_t = nullptr;
@@ -336,7 +336,7 @@ int kfh_create(const kfh_config *cfg, kfh_context **out) {
     if (e == hipSuccess) e = dev_alloc(&c->d_ref_tn, npix);
     if (e == hipSuccess) e = hipMalloc(&c->d_ray_tasks, raycast_task_bytes(c->w, c->h));
     if (e == hipSuccess)
-        e = hipMalloc(reinterpret_cast<void **>(&c->d_integrate_boxes), integrate_box_list_bytes(cfg->vol_res, c->zs1));
+        e = hipMalloc(&c->d_integrate_boxes, integrate_box_list_bytes(cfg->vol_res, c->zs1));
     if (e == hipSuccess && !c->sharded && std::getenv("KFH_NO_BRICK_MARKS") == nullptr)
         e = hipMalloc(reinterpret_cast<void **>(&c->d_bricks), brick_mark_bytes(cfg->vol_res));
     if (e == hipSuccess) e = dev_alloc(&c->d_volume, c->volume_voxels);
@@ -1146,7 +1146,7 @@ int kfh_k_integrate(void *d_volume, const int32_t res[3], const float dim[3], in
     if (e == hipSuccess) e = hipMemsetAsync(d_count, 0, sizeof(unsigned), s);
     if (e == hipSuccess)
         e = launch_integrate(static_cast<short2 *>(d_volume), res, dim, z0, z1, d_depth, w, h, d_inv, Km, mu,
-                             maxweight, nullptr, reinterpret_cast<unsigned *>(scratch + 512), d_count, nullptr, nullptr, s);
+                             maxweight, nullptr, scratch + 512, d_count, nullptr, nullptr, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     (void)hipFree(scratch);
     KFH_HIP(e);
@@ -1161,7 +1161,7 @@ int kfh_k_integrate(void *d_volume, const int32_t res[3], const float dim[3], in
 }  // extern "C"
 
 namespace {
-constexpr size_t KFH_NOALLOC_LIST_BYTES = (size_t)2 << 20;            // 524288 boxes: up to 2048^3 voxels
+constexpr size_t KFH_NOALLOC_LIST_BYTES = (size_t)4 << 20;            // 524288 work items of 8 bytes: up to 2048^3 voxels
 constexpr size_t KFH_NOALLOC_SCRATCH_BYTES = 512 + KFH_NOALLOC_LIST_BYTES;    // [inverse pose | box counter | box list]
 constexpr int KFH_NOALLOC_MAX_DEVICES = 64;
 }  // namespace
@@ -1216,7 +1216,7 @@ int kfh_k_integrate_noalloc(void *d_volume, const int32_t res[3], const float di
     // the matrix travels as a kernel argument and the same launch empties the list left by the previous call
     KFH_HIP(launch_store_mat4(d_inv, inv, d_count, s));
     KFH_HIP(launch_integrate(static_cast<short2 *>(d_volume), res, dim, z0, z1, d_depth, w, h, d_inv, Km, mu, maxweight,
-                             nullptr, reinterpret_cast<unsigned *>(ptr + 512), d_count, nullptr, nullptr, s));
+                             nullptr, ptr + 512, d_count, nullptr, nullptr, s));
     return KFH_OK;
 }
 

@@ -44,6 +44,8 @@ struct Ctrl {
     // launches kept, and plan launches whose gate was open.  A benchmark reads them before and after a run.
     unsigned long long integrate_boxes_total;
     unsigned long long integrate_launches_total;
+    unsigned long long integrate_boxes_before;   // integrate_boxes_total when the last integration started
+    unsigned long long integrate_boxes_last;     // boxes the last integration kept: sizes the next one's work items
     IcpState icp[2];    // alternating records of the ICP loop
 };
 
@@ -167,9 +169,9 @@ hipError_t launch_pose_derive(Ctrl *ctrl, const float k[4], int set_raycast_pose
 size_t integrate_box_list_bytes(const int res[3], int z1);
 hipError_t launch_integrate(short2 *vol, const int res[3], const float dim[3], int z0, int z1,
                             const float *depth, int w, int h, const Mat4 *inv_track, Mat4 K, float mu,
-                            float maxweight, const int *gate, unsigned *boxes, unsigned *box_count,
+                            float maxweight, const int *gate, void *boxes, unsigned *box_count,
                             unsigned char *bricks, const float *tile_max, hipStream_t s,
-                            unsigned long long *totals = nullptr);   // {boxes kept, launches with an open gate} += ...
+                            unsigned long long *totals = nullptr);   // &Ctrl::integrate_boxes_total (the four running totals)
 // voxels of one box of the integrate work list for a volume whose last stored plane is z1 - 1
 int integrate_box_voxels(int z1);
 // One byte per 8^3-voxel brick ("nothing a coarse raycast step could notice in here"): integrate clears marks,

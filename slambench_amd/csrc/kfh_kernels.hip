@@ -1491,7 +1491,13 @@ hipError_t launch_pose_derive(Ctrl *ctrl, const float k[4], int set_raycast_pose
 // A slab [z0, z1) replays the z < z0 additions without touching memory; `vol` starts at plane z0.
 // Algorithmic bytes (convention): 8 B per voxel (4 read + 4 written) x voxels of the slab.
 // =====================================================================================================
-constexpr int INTEGRATE_UNROLL = 8;
+#ifndef KFH_INTEGRATE_UNROLL
+#define KFH_INTEGRATE_UNROLL 8
+#endif
+#ifndef KFH_INTEGRATE_MIN_WAVES
+#define KFH_INTEGRATE_MIN_WAVES 4
+#endif
+constexpr int INTEGRATE_UNROLL = KFH_INTEGRATE_UNROLL;     // z steps a lane keeps in flight
 // smallest raw tsdf for which a trilinear sample is certainly >= 0.8:  26300 * 0.0000305194 = 0.8027, and
 // the interpolation of values >= m stays above m * (1 - 1e-6)
 constexpr int RAY_COARSE_SAFE = 26300;
@@ -1514,14 +1520,19 @@ struct IntegrateArgs {
     const int *gate;            // device flag: 0 = this frame does not integrate
     int zchunk;
     int gx, gy, gz;             // boxes of 64 x 4 x zchunk voxels
-    unsigned *boxes;            // list of box groups that may touch the camera frustum (INTEGRATE_GROUP boxes that
-                                //   follow each other in z): bx | by << 8 | group << 20 | mask of its boxes << 28
+    uint2 *boxes;               // work items: up to 32 boxes of one (bx, by) column that follow each other in z and may
+                                //   touch the camera frustum.  x = bx | by << 8 | first bz << 20 | inside-the-image << 28
+                                //   (every voxel of the item is in front of the camera and projects into the image),
+                                //   y = mask of its boxes
     unsigned *box_count;
+    int min_group;              // boxes per work item: a power of two between min_group and 32, chosen per launch so
+    int target_items;           //   that about target_items items come out (from the previous launch's box count)
     unsigned char *bricks;      // per 8^3 brick: 1 while no voxel of the brick (plus one voxel past it) went
     int bgx, bgy;               //   below RAY_COARSE_SAFE since the last reset; may be null
     const float *tile_max;      // largest depth per preprocessing tile (PRE_TX x PRE_TY pixels, apron included); may be null
     int tiles_x, tiles_y;
-    unsigned long long *totals; // {boxes kept, launches with an open gate} running totals; may be null
+    unsigned long long *totals; // running totals {boxes kept, launches with an open gate, boxes kept up to the previous
+                                //   launch, boxes kept by the previous launch}; may be null
     unsigned long long *dbg;
 };
 
@@ -1529,9 +1540,12 @@ struct IntegrateArgs {
 // two voxels per side.  A voxel is only ever touched if it passes the half-space tests of the march; if all
 // eight corners of the grown box fail the same half-space, no voxel of the box can pass it (the two voxels
 // of slack are far more than the drift of the incrementally accumulated positions).
-__device__ inline bool box_misses_frustum(const IntegrateArgs &a, const Mat4 &invTrack, int bx, int by, int zc0,
-                                          int zc1, const float *tile_max_lds, const float *coarse_max_lds,
-                                          bool depth_test) {
+// Returns 0 when no voxel of the box can be touched, 2 when every voxel of the box certainly lies in front of the
+// camera and projects inside the image (with two pixels to spare: the march may then leave out its own tests),
+// 1 otherwise.
+__device__ inline int box_class(const IntegrateArgs &a, const Mat4 &invTrack, int bx, int by, int zc0,
+                                int zc1, const float *tile_max_lds, const float *coarse_max_lds,
+                                bool depth_test) {
     const float wmax = (float)(a.w - 1), hmax = (float)(a.h - 1);
     const float vx = a.dimx / (float)a.sx, vy = a.dimy / (float)a.sy, vz = a.dimz / (float)a.sz;
     const float bx0 = ((float)(bx * 64 - 2) + 0.5f) * vx;
@@ -1566,7 +1580,12 @@ __device__ inline bool box_misses_frustum(const IntegrateArgs &a, const Mat4 &in
         pxmin = fminf(pxmin, px); pxmax = fmaxf(pxmax, px);
         pymin = fminf(pymin, py); pymax = fmaxf(pymax, py);
     }
-    if (behind || left || right || up || down) return true;
+    if (behind || left || right || up || down) return 0;
+    // Inside the image: with every corner of the grown box in front of the camera, every voxel of the box projects
+    // into the bounding rectangle of the corners' projections (the projection of a convex set in front of the
+    // camera is the convex hull of the projected corners).  The march adds 0.5 and accepts [0, w - 1] x [0, h - 1];
+    // two pixels are kept in hand (the accumulated positions differ from exact ones by far less than a pixel).
+    const bool interior = all_front && pxmin >= 2.f && pxmax <= wmax - 3.f && pymin >= 2.f && pymax <= hmax - 3.f;
     // Behind the surface: a voxel is left untouched when the depth seen through its pixel is at least mu in
     // front of it.  With every corner of the grown box in front of the camera the box projects inside the
     // bounding rectangle of its corners; if even the largest depth of the tiles under that rectangle (4 pixels
@@ -1602,10 +1621,10 @@ __device__ inline bool box_misses_frustum(const IntegrateArgs &a, const Mat4 &in
                     maxd = fmaxf(fmaxf(maxd, fmaxf(v[0], v[1])), fmaxf(v[2], v[3]));
                 }
             }
-            if (zmin - maxd > a.mu + 1e-3f) return true;      // includes "no valid depth at all" for boxes past mu
+            if (zmin - maxd > a.mu + 1e-3f) return 0;         // includes "no valid depth at all" for boxes past mu
         }
     }
-    return false;
+    return interior ? 2 : 1;
 }
 
 // First launch: one thread per box decides whether the box can touch the frustum and appends the survivors
@@ -1616,7 +1635,17 @@ constexpr int KFH_PLAN_MAX_TILES = 256 * KFH_PLAN_TILES_PER_THREAD;     // depth
 // cells of 4 x 4 tiles a plan block holds; narrow, tall images have more cells per tile (160 x 3272 pixels: 5 x 409
 // tiles make 2 x 103 cells), so the depth test is only taken when the cells fit
 constexpr int KFH_PLAN_COARSE_CELLS = KFH_PLAN_MAX_TILES / 16 + 64;
-template <int INTEGRATE_GROUP>     // boxes per work item (consecutive in z): 1, 2 or 4 (mask bits of the packed item)
+// Boxes per work item for this launch.  A work item replays its column's additions from z = 0 up to its first box
+// and then carries them from box to box, so longer items replay less; but fewer, longer items leave the device
+// short of wavefronts while few boxes survive.  The previous integration's box count (frames resemble each other)
+// decides: the smallest power of two that brings the expected number of items down to target_items.
+__device__ inline int integrate_group_size(const IntegrateArgs &a) {
+    const unsigned last = a.totals ? (unsigned)a.totals[3] : 0u;     // only the work launch writes it: stable here
+    int g = a.min_group;
+    while (g < 32 && last / (unsigned)g > (unsigned)a.target_items) g <<= 1;
+    return g;
+}
+
 __global__ __launch_bounds__(256) void k_integrate_plan(IntegrateArgs a) {
     __shared__ float tile_max_lds[KFH_PLAN_MAX_TILES];
     __shared__ float coarse_max_lds[KFH_PLAN_COARSE_CELLS];            // maxima of 4 x 4 tiles
@@ -1630,6 +1659,7 @@ __global__ __launch_bounds__(256) void k_integrate_plan(IntegrateArgs a) {
         tm[k] = depth_test ? a.tile_max[min((int)threadIdx.x + 256 * k, ntiles - 1)] : 0.f;
     const Mat4 inv_track = *a.inv_track;
     const int gate = a.gate ? *a.gate : 1;
+    const int G = integrate_group_size(a);
     if (gate == 0) return;
     if (a.totals && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(a.totals + 1, 1ull);
     if (depth_test) {
@@ -1651,30 +1681,34 @@ __global__ __launch_bounds__(256) void k_integrate_plan(IntegrateArgs a) {
         }
         __syncthreads();
     }
-    // INTEGRATE_GROUP neighbouring lanes hold the boxes of one group (same x and y, consecutive in z); the first
-    // of them appends the group with the mask of its surviving boxes
+    // G neighbouring lanes hold the boxes of one work item (same x and y, consecutive in z); the first of them
+    // appends the item with the mask of its surviving boxes
     const int id = blockIdx.x * blockDim.x + threadIdx.x;
-    const int groups = (a.gz + INTEGRATE_GROUP - 1) / INTEGRATE_GROUP;
-    const int nthreads = a.gx * a.gy * groups * INTEGRATE_GROUP;
-    bool keep = false;
+    const int groups = (a.gz + G - 1) / G;
+    const int nthreads = a.gx * a.gy * groups * G;
+    bool keep = false, edge = false;
     int bx = 0, by = 0, g = 0;
-    const int r = id % INTEGRATE_GROUP;
+    const int r = id & (G - 1);
     if (id < nthreads) {
         // x fastest, then y, then z: the lanes of a wavefront test boxes of similar depth and footprint, and
         // neighbouring items of the list touch neighbouring rows of the volume
-        const int q = id / INTEGRATE_GROUP;
+        const int q = id / G;
         bx = q % a.gx;
         by = (q / a.gx) % a.gy;
         g = q / (a.gx * a.gy);
-        const int bz = g * INTEGRATE_GROUP + r;
+        const int bz = g * G + r;
         const int zc0 = max(a.z0, bz * a.zchunk), zc1 = min(a.z1, (bz + 1) * a.zchunk);
-        keep = bz < a.gz && zc0 < zc1 &&
-               !box_misses_frustum(a, inv_track, bx, by, zc0, zc1, tile_max_lds, coarse_max_lds, depth_test);
+        const int cls = (bz < a.gz && zc0 < zc1)
+                            ? box_class(a, inv_track, bx, by, zc0, zc1, tile_max_lds, coarse_max_lds, depth_test) : 0;
+        keep = cls != 0;
+        edge = cls == 1;
     }
     const unsigned long long m = __ballot(keep);
     if (m) {
         const int lane = threadIdx.x & 63;
-        const unsigned gm = (unsigned)(m >> (lane & ~(INTEGRATE_GROUP - 1))) & ((1u << INTEGRATE_GROUP) - 1u);
+        const unsigned gm = (unsigned)((m >> (lane & ~(G - 1))) & ((1ull << G) - 1ull));
+        // an item whose surviving boxes are all of the "inside the image" kind says so (bit 28)
+        const unsigned ge = (unsigned)((__ballot(edge) >> (lane & ~(G - 1))) & ((1ull << G) - 1ull));
         const bool leader = r == 0 && gm != 0u;
         const unsigned long long lm = __ballot(leader);
         const int first = __ffsll((long long)lm) - 1;
@@ -1686,15 +1720,23 @@ __global__ __launch_bounds__(256) void k_integrate_plan(IntegrateArgs a) {
         base = __builtin_amdgcn_readlane(base, first);
         if (leader)
             a.boxes[base + __popcll(lm & ((1ull << lane) - 1ull))] =
-                (unsigned)bx | ((unsigned)by << 8) | ((unsigned)g << 20) | (gm << 28);
+                make_uint2((unsigned)bx | ((unsigned)by << 8) | ((unsigned)(g * G) << 20) | (ge == 0u ? 1u << 28 : 0u), gm);
     }
 }
 
 // Second launch: a workgroup takes boxes from the list; one thread per (x, y) column of the box.
-template <int INTEGRATE_GROUP>
-__global__ __launch_bounds__(256) void k_integrate(IntegrateArgs a) {
+__global__ __launch_bounds__(256, KFH_INTEGRATE_MIN_WAVES) void k_integrate(IntegrateArgs a) {
     if (!KFH_STAMPS_COMPILED) a.dbg = nullptr;      // per-wavefront statistics only in diagnostic builds
     const unsigned nbox = *a.box_count;
+    if (a.totals && blockIdx.x == 0 && threadIdx.x == 0) {
+        // the plan launch has ended: what it added to the running total is this integration's box count, which
+        // the next plan launch sizes its work items by
+        const unsigned long long t = a.totals[0];
+        if (t != a.totals[2]) {
+            a.totals[3] = t - a.totals[2];
+            a.totals[2] = t;
+        }
+    }
     if (nbox == 0) return;
     // diagnostics (dbg != null): per box and wavefront {start, end} of the 100 MHz counter, candidates, written
     const Mat4 invTrack = *a.inv_track;
@@ -1710,15 +1752,19 @@ __global__ __launch_bounds__(256) void k_integrate(IntegrateArgs a) {
         unsigned long long dbg_t0 = 0;
         unsigned dbg_cand = 0, dbg_written = 0;
         if (a.dbg) dbg_t0 = __builtin_amdgcn_s_memrealtime();
-        const unsigned box = a.boxes[bi];
-        const int bx = box & 0xFF, by = (box >> 8) & 0xFFF, group = (box >> 20) & 0xFF;
-        const unsigned group_mask = box >> 28;
+        const uint2 item = a.boxes[bi];
+        const int bx = item.x & 0xFF, by = (item.x >> 8) & 0xFFF, first_bz = (item.x >> 20) & 0xFF;
+        unsigned group_mask = item.y;
+        const bool item_inside = (item.x >> 28) & 1u;
         const int x = bx * 64 + (threadIdx.x & 63);
         const int y = by * 4 + (threadIdx.x >> 6);
         const bool in_vol = x < sx && y < sy;
         const f3 p0 = mk3(((float)x + 0.5f) * dimx / (float)sx, ((float)y + 0.5f) * dimy / (float)sy,
                           (0.0f + 0.5f) * dimz / (float)sz);
-        short2 *col = a.vol + (size_t)min(x, sx - 1) + (size_t)min(y, sy - 1) * sx;
+        // a voxel's address is a plane address (the same for the whole block: scalar registers) plus the column's
+        // 32-bit offset inside a plane
+        // (as a byte offset: a plane of at most 4096 x 4096 voxels takes 2^26 bytes)
+        const unsigned col = ((unsigned)min(x, sx - 1) + (unsigned)min(y, sy - 1) * (unsigned)sx) * (unsigned)sizeof(short2);
         // The reference accumulates the camera-space position of a column step by step from z = 0.  The same
         // additions in the same order are replayed up to each box, two components per packed add; the boxes of a
         // group follow each other in z, so the replay is paid once per group and carried from box to box.
@@ -1731,9 +1777,9 @@ __global__ __launch_bounds__(256) void k_integrate(IntegrateArgs a) {
         }
         const v2f d0 = {delta.x, delta.y}, d1 = {delta.z, cameraDelta.x}, d2 = {cameraDelta.y, cameraDelta.z};
         int zacc = 0;                    // the accumulators hold the state of step zacc
-        for (int r = 0; r < INTEGRATE_GROUP; ++r) {
-            if (!((group_mask >> r) & 1u)) continue;
-            const int bz = group * INTEGRATE_GROUP + r;
+        while (group_mask) {
+            const int bz = first_bz + __ffs(group_mask) - 1;
+            group_mask &= group_mask - 1u;
             const int zc0 = max(a.z0, bz * a.zchunk);
             const int zc1 = min(a.z1, (bz + 1) * a.zchunk);
 #pragma unroll 8
@@ -1743,54 +1789,68 @@ __global__ __launch_bounds__(256) void k_integrate(IntegrateArgs a) {
                 acc2 += d2;
             }
             zacc = zc0;
-            f3 pos = mk3(acc0.x, acc0.y, acc1.x);
-            f3 cameraX = mk3(acc1.y, acc2.x, acc2.y);
-            // INTEGRATE_UNROLL z steps are advanced arithmetically, then their depth pixels and voxels are fetched
-            // together (the voxel read is issued as soon as the pixel test passes, before the depth value is
-            // known) and finally updated: one memory round trip per batch of steps instead of two per voxel.
+            // A box that is not a whole number of batches (the first or last box of a z-slab) leaves the accumulators
+            // past its end: the next box then replays from z = 0 (rare, and cheaper than carrying copies in registers)
+            const bool whole_batches = ((zc1 - zc0) & (INTEGRATE_UNROLL - 1)) == 0;
+            // INTEGRATE_UNROLL z steps are advanced arithmetically (the same packed additions as the replay), then
+            // their depth pixels and voxels are fetched together (the voxel read is issued as soon as the pixel test
+            // passes, before the depth value is known) and finally updated: one memory round trip per batch of
+            // steps instead of two per voxel.
+            auto march = [&](auto inside_tag) {
+            constexpr bool INSIDE = decltype(inside_tag)::value;
             for (int zb = zc0; zb < zc1; zb += INTEGRATE_UNROLL) {
-                f3 posk[INTEGRATE_UNROLL];
-                float camz[INTEGRATE_UNROLL];
+                v2f posxy[INTEGRATE_UNROLL];
+                float posz[INTEGRATE_UNROLL], camz[INTEGRATE_UNROLL];
                 unsigned pidx[INTEGRATE_UNROLL];
                 bool cand[INTEGRATE_UNROLL];
 #pragma unroll
                 for (int u = 0; u < INTEGRATE_UNROLL; ++u) {
                     const int z = zb + u;
-                    posk[u] = pos;
-                    camz[u] = cameraX.z;
-                    bool c = in_vol && z < zc1 && !(pos.z < 0.0001f);
+                    const float pz = acc1.x, cx = acc1.y, cy = acc2.x, cz = acc2.y;
+                    posxy[u] = acc0;
+                    posz[u] = pz;
+                    camz[u] = cz;
+                    // INSIDE: the plan launch has shown that every voxel of the item lies in front of the camera and
+                    // projects inside the image, so the reference's tests all pass and are left out
+                    bool c = in_vol && z < zc1 && (INSIDE || !(pz < 0.0001f));
                     // Cheap conservative rejection (one pixel of slack, far above the rounding of the exact test):
                     // a voxel that fails it cannot pass the exact in-image test below.
-                    if (c && (cameraX.x < -1.5f * cameraX.z || cameraX.x > (wmax + 1.5f) * cameraX.z ||
-                              cameraX.y < -1.5f * cameraX.z || cameraX.y > (hmax + 1.5f) * cameraX.z))
+                    if (!INSIDE && c && (cx < -1.5f * cz || cx > (wmax + 1.5f) * cz || cy < -1.5f * cz || cy > (hmax + 1.5f) * cz))
                         c = false;
                     unsigned pi = 0;
                     if (c) {
-                        const float r1 = refined_rcp(cameraX.z);
-                        const float pxf = div_shared(cameraX.x, cameraX.z, r1) + 0.5f;
-                        const float pyf = div_shared(cameraX.y, cameraX.z, r1) + 0.5f;
-                        if (pxf < 0 || pxf > wmax || pyf < 0 || pyf > hmax) c = false;
+                        const float r1 = refined_rcp(cz);
+                        const float pxf = div_shared(cx, cz, r1) + 0.5f;
+                        const float pyf = div_shared(cy, cz, r1) + 0.5f;
+                        if (!INSIDE && (pxf < 0 || pxf > wmax || pyf < 0 || pyf > hmax)) c = false;
                         else pi = (unsigned)pxf + (unsigned)pyf * (unsigned)w;
                     }
                     cand[u] = c;
                     pidx[u] = pi;
-                    pos = pos + delta;
-                    cameraX = cameraX + cameraDelta;
+                    acc0 += d0;
+                    acc1 += d1;
+                    acc2 += d2;
                 }
                 float dk[INTEGRATE_UNROLL];
                 short2 rawk[INTEGRATE_UNROLL];
+                short2 *const zplane = a.vol + (size_t)(zb - a.z0) * plane;
+                {
+                    const short2 *pz = zplane;
 #pragma unroll
-                for (int u = 0; u < INTEGRATE_UNROLL; ++u) {
-                    dk[u] = 0.f;
-                    rawk[u] = make_short2(0, 0);
-                    if (cand[u]) {
-                        dk[u] = depth[pidx[u]];
-                        rawk[u] = col[(size_t)(zb + u - a.z0) * plane];
+                    for (int u = 0; u < INTEGRATE_UNROLL; ++u) {
+                        dk[u] = 0.f;
+                        rawk[u] = make_short2(0, 0);
+                        if (cand[u]) {
+                            dk[u] = depth[pidx[u]];
+                            rawk[u] = *reinterpret_cast<const short2 *>(reinterpret_cast<const char *>(pz) + col);
+                        }
+                        pz += plane;
+                        if (a.dbg) dbg_cand += __popcll(__ballot(cand[u]));
                     }
-                    if (a.dbg) dbg_cand += __popcll(__ballot(cand[u]));
                 }
+                short2 *pz_out = zplane;
 #pragma unroll
-                for (int u = 0; u < INTEGRATE_UNROLL; ++u) {
+                for (int u = 0; u < INTEGRATE_UNROLL; ++u, pz_out += plane) {
                     if (!cand[u] || dk[u] == 0) continue;
                     // diff = (d - z) * s with s = sqrt(1 + rx^2 + ry^2) >= 1, so
                     //   d - z <= -mu  implies  diff <= -mu        (voxel behind the surface: untouched)
@@ -1800,21 +1860,31 @@ __global__ __launch_bounds__(256) void k_integrate(IntegrateArgs a) {
                     if (dz <= -mu) continue;
                     float sdf = 1.f;
                     if (dz < mu) {
-                        const float r1 = refined_rcp(posk[u].z);
-                        const float rx = div_shared(posk[u].x, posk[u].z, r1), ry = div_shared(posk[u].y, posk[u].z, r1);
+                        const float r1 = refined_rcp(posz[u]);
+                        const float rx = div_shared(posxy[u].x, posz[u], r1), ry = div_shared(posxy[u].y, posz[u], r1);
                         const float diff = dz * sqrtf(1 + rx * rx + ry * ry);
                         if (!(diff > -mu)) continue;
                         sdf = fminf(1.f, diff / mu);
                     }
                     {
-                        float tsdf = (float)rawk[u].x * KFH_SHORT2FLOAT;
-                        float wgt = (float)rawk[u].y;
-                        tsdf = fmaxf(-1.f, fminf((wgt * tsdf + sdf) / (wgt + 1), 1.f));
-                        wgt = fminf(wgt + 1, maxweight);
-                        const short2 out = make_short2((short)(tsdf * KFH_FLOAT2SHORT), (short)wgt);
+                        short2 out;
+                        if (sdf == 1.f && rawk[u].x == 32766 && rawk[u].y >= 0) {
+                            // Free space seen as free space again.  32766 * KFH_SHORT2FLOAT is exactly 1.0f, so the
+                            // reference's (w * 1 + 1) / (w + 1) is (w + 1) / (w + 1) = 1 for every weight w >= 0
+                            // (all of w, w + 1 are exact integers in float): the value stays 32766 without any
+                            // arithmetic, only the weight moves.
+                            static_assert(32766.0f * KFH_SHORT2FLOAT == 1.0f, "the free-space shortcut needs 32766 -> 1.0f");
+                            out = make_short2((short)32766, (short)fminf((float)rawk[u].y + 1, maxweight));
+                        } else {
+                            float tsdf = (float)rawk[u].x * KFH_SHORT2FLOAT;
+                            float wgt = (float)rawk[u].y;
+                            tsdf = fmaxf(-1.f, fminf((wgt * tsdf + sdf) / (wgt + 1), 1.f));
+                            wgt = fminf(wgt + 1, maxweight);
+                            out = make_short2((short)(tsdf * KFH_FLOAT2SHORT), (short)wgt);
+                        }
                         // free space seen often enough stays at (1, maxweight): nothing to store then
                         if (out.x != rawk[u].x || out.y != rawk[u].y) {
-                            col[(size_t)(zb + u - a.z0) * plane] = out;
+                            *reinterpret_cast<short2 *>(reinterpret_cast<char *>(pz_out) + col) = out;
                             if (a.dbg) ++dbg_written;
                         }
                         // The voxel drops below the level that lets a coarse raycast step pass unseen: every brick
@@ -1832,7 +1902,18 @@ __global__ __launch_bounds__(256) void k_integrate(IntegrateArgs a) {
                     }
                 }
             }
-            }   // boxes of the group
+            };
+            if (item_inside) march(std::true_type{}); else march(std::false_type{});
+            // the march has advanced the accumulators itself: after whole batches they hold the state of step zc1
+            if (whole_batches) {
+                zacc = zc1;
+            } else {
+                const f3 pos0 = xform(invTrack, p0);
+                const f3 cam0 = xform(K, pos0);
+                acc0 = v2f{pos0.x, pos0.y}; acc1 = v2f{pos0.z, cam0.x}; acc2 = v2f{cam0.y, cam0.z};
+                zacc = 0;
+            }
+            }   // boxes of the item
         if (a.dbg) {
             unsigned long long tot = dbg_written;
             for (int m = 32; m >= 1; m >>= 1) tot += __shfl_xor(tot, m, 64);
@@ -1858,24 +1939,30 @@ static int integrate_zchunk(int z1) {
     return z1 <= 512 ? 16 : z1 <= 1024 ? 32 : 64;
 }
 
-// Boxes per work item: the replay of a column's additions is paid once per item, but fewer and longer items
-// leave the device short of wavefronts while the volume is small.  KFH_INTEGRATE_GROUP overrides it for experiments.
-static int integrate_group(int z1) {
+// Smallest number of boxes per work item (a power of two up to 32; the plan launch raises it when the previous
+// integration kept many boxes).  Up to 1024 planes single boxes are best while few survive; beyond that the replay
+// of a column's additions (up to thousands of steps) outweighs the loss of wavefronts.  KFH_INTEGRATE_GROUP
+// overrides it, KFH_INTEGRATE_TARGET_ITEMS the number of work items the plan launch aims for.
+static int integrate_min_group(int z1) {
     static const int forced = std::getenv("KFH_INTEGRATE_GROUP") ? std::atoi(std::getenv("KFH_INTEGRATE_GROUP")) : 0;
-    if (forced == 1 || forced == 2 || forced == 4) return forced;
+    if (forced >= 1 && forced <= 32 && (forced & (forced - 1)) == 0) return forced;
     return z1 <= 1024 ? 1 : 4;
+}
+static int integrate_target_items() {
+    static const int forced = std::getenv("KFH_INTEGRATE_TARGET_ITEMS") ? std::atoi(std::getenv("KFH_INTEGRATE_TARGET_ITEMS")) : 0;
+    return forced > 0 ? forced : 4096;
 }
 
 int integrate_box_voxels(int z1) { return 64 * 4 * integrate_zchunk(z1); }
 
 size_t integrate_box_list_bytes(const int res[3], int z1) {
     const int zchunk = integrate_zchunk(z1);
-    return (size_t)((res[0] + 63) / 64) * ((res[1] + 3) / 4) * ((z1 + zchunk - 1) / zchunk) * sizeof(unsigned);
+    return (size_t)((res[0] + 63) / 64) * ((res[1] + 3) / 4) * ((z1 + zchunk - 1) / zchunk) * sizeof(uint2);
 }
 
 hipError_t launch_integrate(short2 *vol, const int res[3], const float dim[3], int z0, int z1,
                             const float *depth, int w, int h, const Mat4 *inv_track, Mat4 K, float mu,
-                            float maxweight, const int *gate, unsigned *boxes, unsigned *box_count,
+                            float maxweight, const int *gate, void *boxes, unsigned *box_count,
                             unsigned char *bricks, const float *tile_max, hipStream_t s,
                             unsigned long long *totals) {
     // Short z chunks: boxes that miss the camera frustum never reach the work launch, the others replay the
@@ -1889,26 +1976,19 @@ hipError_t launch_integrate(short2 *vol, const int res[3], const float dim[3], i
     a.inv_track = inv_track; a.K = K; a.mu = mu; a.maxweight = maxweight; a.gate = gate;
     a.zchunk = integrate_zchunk(z1);
     a.gx = (res[0] + 63) / 64; a.gy = (res[1] + 3) / 4; a.gz = (z1 + a.zchunk - 1) / a.zchunk;
-    a.boxes = boxes; a.box_count = box_count;
+    a.boxes = static_cast<uint2 *>(boxes); a.box_count = box_count;
+    a.min_group = integrate_min_group(z1); a.target_items = integrate_target_items();
     a.bricks = bricks; a.bgx = (res[0] + 7) / 8; a.bgy = (res[1] + 7) / 8;
     a.tile_max = tile_max; a.tiles_x = (w + PRE_TX - 1) / PRE_TX; a.tiles_y = (h + PRE_TY - 1) / PRE_TY;
     a.totals = totals;
     a.dbg = g_integrate_debug;
-    const int group = integrate_group(z1);
-    const int groups = (a.gz + group - 1) / group;
-    if (a.gx > 256 || a.gy > 4096 || groups > 256) return hipErrorInvalidValue;   // packed item
-    const int nitems = a.gx * a.gy * groups;          // plan: `group` threads per item
-    const dim3 plan_grid((nitems * group + 255) / 256), work_grid(nitems < 2048 ? nitems : 2048);
-    if (group == 4) {
-        hipLaunchKernelGGL(k_integrate_plan<4>, plan_grid, dim3(256), 0, s, a);
-        hipLaunchKernelGGL(k_integrate<4>, work_grid, dim3(256), 0, s, a);
-    } else if (group == 2) {
-        hipLaunchKernelGGL(k_integrate_plan<2>, plan_grid, dim3(256), 0, s, a);
-        hipLaunchKernelGGL(k_integrate<2>, work_grid, dim3(256), 0, s, a);
-    } else {
-        hipLaunchKernelGGL(k_integrate_plan<1>, plan_grid, dim3(256), 0, s, a);
-        hipLaunchKernelGGL(k_integrate<1>, work_grid, dim3(256), 0, s, a);
-    }
+    if (a.gx > 256 || a.gy > 4096 || a.gz > 256) return hipErrorInvalidValue;   // packed item
+    // the plan launch decides its group size itself (1 to 32 lanes per work item): threads for the widest layout
+    const int plan_threads = a.gx * a.gy * ((a.gz + 31) / 32) * 32;
+    const int nitems = a.gx * a.gy * ((a.gz + a.min_group - 1) / a.min_group);
+    const dim3 plan_grid((plan_threads + 255) / 256), work_grid(nitems < 2048 ? nitems : 2048);
+    hipLaunchKernelGGL(k_integrate_plan, plan_grid, dim3(256), 0, s, a);
+    hipLaunchKernelGGL(k_integrate, work_grid, dim3(256), 0, s, a);
     return hipGetLastError();
 }
 

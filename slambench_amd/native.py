@@ -9,7 +9,8 @@ import os
 from .config import KfhConfig
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libkfusion_hip_core.so")
+# KFH_CORE_LIB: another build of the same library (the diagnostic one: make -C slambench_amd/csrc STAMPS=1)
+LIB_PATH = os.environ.get("KFH_CORE_LIB") or os.path.join(_HERE, "lib", "libkfusion_hip_core.so")
 
 KFH_OK = 0
 BUF_FLOAT_DEPTH, BUF_SCALED_DEPTH, BUF_INPUT_VERTEX, BUF_INPUT_NORMAL = 0, 1, 2, 3

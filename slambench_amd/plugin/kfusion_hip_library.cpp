@@ -9,6 +9,8 @@
 // Parameter names, defaults and short options are those of the kfusion use-case as printed in the reference's
 // logs (icra2018_results/1080/violons_libkfusion-cpp_living_room_traj0_loop.log:20-31); phase names are the
 // Duration_* columns of the same log (:36).
+#include <limits>      // SLAMBench's Parameters.h uses std::numeric_limits without including it (an error from GCC 11 on)
+
 #include <SLAMBenchAPI.h>
 #include <io/SLAMFrame.h>
 #include <io/sensor/CameraSensor.h>

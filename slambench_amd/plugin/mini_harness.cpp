@@ -13,9 +13,19 @@
 //  * a .slam file, SLAMBench's own dataset container (header: reference
 //    framework/shared/src/io/serialisation/SLAMFileHeaderSerialiser.cpp:34-44, sensors: io/sensor/Sensor.cpp:77-97,
 //    CameraSensor.cpp:66-79, DepthSensor.cpp:38-56, GroundTruthSensor.cpp:23-37, frames:
-//    io/serialisation/SLAMFrameSerialiser.cpp:21-55).  Camera, Depth and GroundTruthTrajectory sensors are
-//    understood; ground-truth frames are filtered out before the plugin, as the reference's frame loop does
-//    (SLAMBenchConfiguration.cpp:254-262); any other sensor type ends the run with an error.
+//    io/serialisation/SLAMFrameSerialiser.cpp:21-55).  Every sensor type the reference registers is read
+//    (Camera, Depth, GroundTruthTrajectory, Accelerometer, Gyro, IMU, Odom, Lidar, PointCloud, EventCamera; the
+//    last three have a u32 byte count in front of every frame, io/deserialisation/SLAMFileDeserialiser.cpp:56-79);
+//    ground-truth trajectory frames are filtered out before the plugin, as the reference's frame loop does
+//    (SLAMBenchConfiguration.cpp:252), all other frames are handed to it, which is what makes a depth-only
+//    plugin say "not mine" to the accelerometer frames of a TUM file.
+//
+// -fl N counts processed frame-sets and -s N skips the first N frame-sets.  With --reference-frame-limit both
+// count the way the reference does (SLAMBenchConfiguration.cpp:251-256, :322-324): its counter goes up by one for
+// every frame taken from the file, of whatever sensor, and by one more for every processed frame-set; frames are
+// withheld from the plugin while the counter is below 3 * N of -s, and the run ends when it reaches -fl.  With
+// RGB, Depth and Grey streams "-fl 30" so processes 7 or 8 frame-sets; a run that is to be compared with one of the
+// reference's logs needs the switch.
 //  * a .kfd file (this repository's raw depth container, written by slambench_amd/harness.py):
 //    char magic[4] = "KFD1"; uint32 width, height, frames; float fx, fy, cx, cy (normalised by width/height);
 //    float depth_scale (raw unit -> metres); then per frame: double timestamp_s; uint16 depth[height][width].
@@ -64,8 +74,8 @@ static bool parse_plugin_options(SLAMBenchLibraryHelper *lib, const std::vector<
 
 int main(int argc, char **argv) {
     std::string input, library, log_file, dump_frames;
-    int frame_limit = 0;
-    bool dse = false;
+    int frame_limit = 0, start_frame = 0;
+    bool dse = false, reference_counting = false;
     std::vector<std::string> plugin_args;
     for (int i = 1; i < argc; ++i) {
         const std::string a = argv[i];
@@ -74,12 +84,14 @@ int main(int argc, char **argv) {
         else if (a == "-load" || a == "--load-library") library = need("-load");
         else if (a == "-o" || a == "--log-file") log_file = need("-o");
         else if (a == "-fl" || a == "--frame-limit") frame_limit = std::atoi(need("-fl").c_str());
+        else if (a == "-s" || a == "--start-frame") start_frame = std::atoi(need("-s").c_str());
+        else if (a == "--reference-frame-limit") reference_counting = true;
         else if (a == "--dump-frames") dump_frames = need("--dump-frames");
         else if (a == "-dse" || a == "--dse") dse = true;
         else plugin_args.push_back(a);
     }
     if (input.empty() || library.empty()) {
-        std::fprintf(stderr, "usage: %s -i stream.{slam,kfd} -load libkfusion-hip-library.so [-fl N] [-o log] [--dump-frames DIR] [--dse] [plugin options]\n", argv[0]);
+        std::fprintf(stderr, "usage: %s -i stream.{slam,kfd} -load libkfusion-hip-library.so [-fl N] [-s N] [--reference-frame-limit] [-o log] [--dump-frames DIR] [--dse] [plugin options]\n", argv[0]);
         return 1;
     }
 
@@ -93,7 +105,8 @@ int main(int argc, char **argv) {
 
     sio::InputInterface interface;
     std::vector<sio::Sensor *> file_sensors;       // by file index (.slam)
-    std::vector<size_t> frame_sizes;
+    std::vector<size_t> frame_sizes;                // payload bytes; 0 with counted[] set: the count in front decides
+    std::vector<bool> counted;                      // a u32 byte count precedes every frame (variable-size sensors)
     uint32_t w = 0, h = 0, n = 0;
     float intr[4] = {0, 0, 0, 0}, depth_scale = 0.f;
     sio::CameraSensor *rgb = nullptr, *grey = nullptr;
@@ -141,6 +154,7 @@ int main(int argc, char **argv) {
             if (!in) { std::fprintf(stderr, "%s: truncated sensor block\n", input.c_str()); return 1; }
             sio::Sensor *sensor = nullptr;
             size_t frame_size = 0;
+            bool counted_now = false;
             if (type == "Camera" || type == "Depth") {
                 int32_t frame_format = 0, pixel_format = 0;
                 uint32_t sw = 0, sh = 0;
@@ -166,17 +180,47 @@ int main(int argc, char **argv) {
                 frame_size = cam->GetFrameSize();
                 sensor = cam;
                 interface.GetSensors().AddSensor(cam);
-            } else if (type == "GroundTruthTrajectory") {
-                sensor = new sio::Sensor(name, type);
-                frame_size = 64;
             } else {
-                std::fprintf(stderr, "%s: sensor '%s' has type '%s', which this loader does not read\n", input.c_str(),
-                             name.c_str(), type.c_str());
-                return 1;
+                // the other sensor types: bytes of their own block, payload bytes of a frame (0 = the count in
+                // front of the frame), whether such a count is there (the reference's "variable size" flag)
+                static const struct { const char *type; size_t block, frame; bool has_count; } kinds[] = {
+                    {"GroundTruthTrajectory", 0, 64, false},   // GroundTruthSensor.cpp:21-24
+                    {"Accelerometer", 72, 12, false},          // AccelerometerSensor.cpp:23-35
+                    {"Gyro", 72, 12, false},                   // GyroSensor.cpp:22-34
+                    {"IMU", 32, 24, false},                    // IMUSensor.cpp:22-44
+                    {"Odom", 0, 52, false},                    // OdomSensor.cpp:19-31
+                    {"Lidar", 36, 0, true},                    // LidarSensor.cpp:25-53
+                    {"PointCloud", 0, 0, true},                // PointCloudSensor.cpp:21-31
+                    {"EventCamera", 8, 0, true},               // EventCameraSensor.cpp:25-42 (frame size below)
+                };
+                bool known = false;
+                for (const auto &k : kinds) {
+                    if (type != k.type) continue;
+                    known = true;
+                    unsigned char block[72];
+                    rd(block, k.block);
+                    frame_size = k.frame;
+                    counted_now = k.has_count;
+                    if (type == "EventCamera") {               // x, y, on/off; coordinates as narrow as the sensor allows
+                        int32_t ew = 0, eh = 0;
+                        std::memcpy(&ew, block, 4); std::memcpy(&eh, block + 4, 4);
+                        const size_t coord = (ew <= 0xFF && eh <= 0xFF) ? 1 : (ew <= 0xFFFF && eh <= 0xFFFF) ? 2 : 4;
+                        frame_size = 2 * coord + 1;
+                    }
+                }
+                if (!known) {
+                    std::fprintf(stderr, "%s: sensor '%s' has type '%s', which the reference does not register\n",
+                                 input.c_str(), name.c_str(), type.c_str());
+                    return 1;
+                }
+                sensor = new sio::Sensor(name, type);
+                sensor->Rate = rate;
+                if (type != "GroundTruthTrajectory") interface.GetSensors().AddSensor(sensor);
             }
             if (!in) { std::fprintf(stderr, "%s: truncated sensor block\n", input.c_str()); return 1; }
             file_sensors.push_back(sensor);
             frame_sizes.push_back(frame_size);
+            counted.push_back(counted_now);
         }
     }
 
@@ -279,15 +323,24 @@ int main(int argc, char **argv) {
         }
     } else {
         std::vector<unsigned char> payload;
+        unsigned frame_count = 0;                 // the reference's counter (SLAMBenchConfiguration.cpp:239)
+        unsigned sets_seen = 0;                   // frame-sets completed or skipped (the plain counting)
         while (true) {
             struct __attribute__((packed)) { uint32_t s, ns; uint8_t index; } head;
             in.read((char *)&head, sizeof(head));
             if (in.gcount() == 0) break;                      // clean end of file
             if (!in || head.index >= file_sensors.size()) { std::fprintf(stderr, "bad frame header\n"); return 1; }
-            payload.resize(frame_sizes[head.index]);
+            size_t size = frame_sizes[head.index];
+            if (counted[head.index]) {
+                uint32_t bytes = 0;
+                in.read((char *)&bytes, 4);
+                if (size == 0) size = bytes;
+            }
+            payload.resize(size);
             in.read((char *)payload.data(), (std::streamsize)payload.size());
             if (!in) { std::fprintf(stderr, "truncated frame payload\n"); return 1; }
             sio::Sensor *sensor = file_sensors[head.index];
+            ++frame_count;
             if (sensor->GetType() == "GroundTruthTrajectory") continue;     // kept from the algorithms
             const slambench::TimeStamp ts = slambench::TimeStamp::get(head.s, head.ns);
             sio::SLAMInMemoryFrame fr;
@@ -295,8 +348,22 @@ int main(int argc, char **argv) {
             fr.Data = payload.data();
             fr.Size = payload.size();
             fr.Timestamp = ts;
-            if (feed(&fr, ts) < 0) return 1;
-            if (frame_limit > 0 && processed >= (unsigned)frame_limit) break;
+            if (reference_counting) {
+                if (frame_count < (unsigned)start_frame * 3) continue;
+                const int fed = feed(&fr, ts);
+                if (fed < 0) return 1;
+                if (fed > 0) {
+                    ++frame_count;
+                    if (frame_limit > 0 && frame_count >= (unsigned)frame_limit) break;
+                }
+            } else {
+                if (sets_seen < (unsigned)start_frame) {           // -s: whole frame-sets are skipped, told by their depth frame
+                    if (sensor->GetType() == "Depth") ++sets_seen;
+                    continue;
+                }
+                if (feed(&fr, ts) < 0) return 1;
+                if (frame_limit > 0 && processed >= (unsigned)frame_limit) break;
+            }
         }
     }
     if (!dump_frames.empty()) {

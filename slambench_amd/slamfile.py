@@ -1,4 +1,5 @@
-"""Reader and writer of SLAMBench's `.slam` dataset container, for the sensors a depth-only plugin meets.
+"""Reader and writer of SLAMBench's `.slam` dataset container: every sensor type the reference registers is
+parsed (a depth-only plugin uses Depth and the ground truth and steps over the frames of the others).
 
 Layout (little endian, no padding), as the reference serialises it:
   header   "SLAM\\0" (5 bytes), u32 version = 1, u32 sensor count
@@ -16,13 +17,23 @@ Layout (little endian, no padding), as the reference serialises it:
                            (reference framework/shared/src/io/sensor/DepthSensor.cpp:38-56)
     GroundTruthTrajectory  nothing; its frames are 4x4 f32 poses, column-major
                            (reference framework/shared/src/io/sensor/GroundTruthSensor.cpp:23-37)
-  frames   until end of file: u32 seconds, u32 nanoseconds, u8 sensor index, payload of the sensor's frame size
-           (none of the three sensor types above is variable-sized)
+    Accelerometer, Gyro    12 x f32 intrinsic, 3 x f32 noise variances, 3 x f32 bias variances; frames 3 x f32
+                           (reference framework/shared/src/io/sensor/AccelerometerSensor.cpp:23-35, GyroSensor.cpp:22-34;
+                            the TUM generator adds an Accelerometer by default, tools/dataset-tools/TUM.cpp:340-389)
+    IMU                    8 x f32 noise / saturation figures; frames 6 x f32 (IMUSensor.cpp:22-44)
+    Odom                   nothing; frames 13 x f32 (OdomSensor.cpp:19-31)
+    Lidar                  f32 points per cycle, f32 altitude, 2 x f32 + 2 x f32 fields of view, 2 x f32 angular
+                           resolutions, i32 beams; variable-size frames (LidarSensor.cpp:25-53, :84)
+    PointCloud             nothing; variable-size frames: u32 count + count x 3 x f32; a ground-truth sensor
+                           (PointCloudSensor.cpp:21-53, io/format/PointCloud.cpp:17-48; the ICL-NUIM generator adds
+                            one when given a .ply, tools/dataset-tools/ICLNUIM.cpp:388-406)
+    EventCamera            i32 width, i32 height; registered as variable-size, payload 2 coordinates of 1, 2 or 4
+                           bytes (by sensor size) + 1 byte (EventCameraSensor.cpp:25-42, :73)
+  frames   until end of file: u32 seconds, u32 nanoseconds, u8 sensor index, then for a variable-size sensor a u32
+           byte count, then the payload (the count for a variable-size sensor whose frame size follows it, else
+           the sensor's fixed frame size)
            (reference framework/shared/src/io/serialisation/SLAMFrameSerialiser.cpp:21-55,
             framework/shared/src/io/deserialisation/SLAMFileDeserialiser.cpp:56-79)
-
-Other sensor types of the reference (IMU, lidar, event camera, ...) are refused: their frame sizes come from
-blocks this module does not parse.
 """
 import struct
 from dataclasses import dataclass, field
@@ -39,6 +50,20 @@ PIXEL_SIZE = {0: 0, 1: 1, 2: 3, 3: 1, 4: 4, 5: 2, 6: 8, 7: 4}
 FRAME_FORMAT_RASTER = 1
 
 CAMERA, DEPTH, GROUND_TRUTH = "Camera", "Depth", "GroundTruthTrajectory"
+ACCELEROMETER, GYRO, IMU, ODOM, LIDAR, POINT_CLOUD, EVENT_CAMERA = ("Accelerometer", "Gyro", "IMU", "Odom", "Lidar",
+                                                                    "PointCloud", "EventCamera")
+# type -> (struct format of the type's own block, fixed frame size in bytes or None, variable-size flag of the
+# reference's sensor database, ground-truth flag); Camera / Depth / EventCamera sizes depend on the block
+_SIMPLE_SENSORS = {
+    GROUND_TRUTH: ("", 64, False, True),
+    ACCELEROMETER: ("<18f", 12, False, False),
+    GYRO: ("<18f", 12, False, False),
+    IMU: ("<8f", 24, False, False),
+    ODOM: ("", 52, False, False),
+    LIDAR: ("<8fi", None, True, False),
+    POINT_CLOUD: ("", None, True, True),
+    EVENT_CAMERA: ("<ii", None, True, False),
+}
 
 
 @dataclass
@@ -61,14 +86,30 @@ class Sensor:
     # depth
     disparity_params: tuple = (0.001, 0.0)             # raw unit -> metres: d * p[0] + p[1]
     disparity_type: int = 0
+    # the other sensor types: the values of their own block, in file order (zeros when written without)
+    block: tuple = ()
+
+    @property
+    def variable_size(self):
+        """The reference's sensor database flag: a u32 byte count precedes every frame of the sensor."""
+        return self.type in _SIMPLE_SENSORS and _SIMPLE_SENSORS[self.type][2]
+
+    @property
+    def is_ground_truth(self):
+        return self.type in _SIMPLE_SENSORS and _SIMPLE_SENSORS[self.type][3]
 
     @property
     def frame_size(self):
+        """Payload bytes of a frame; None when the count in front of each frame decides (Lidar, PointCloud)."""
         if self.type in (CAMERA, DEPTH):
             return self.width * self.height * PIXEL_SIZE[self.pixel_format]
-        if self.type == GROUND_TRUTH:
-            return 64
-        raise ValueError("sensor type %r is not supported" % self.type)
+        if self.type == EVENT_CAMERA:                  # x, y, on/off (EventCameraSensor.cpp:25-35)
+            w, h = self.block[:2] if len(self.block) >= 2 else (self.width, self.height)
+            coord = 1 if (w <= 0xFF and h <= 0xFF) else 2 if (w <= 0xFFFF and h <= 0xFFFF) else 4
+            return 2 * coord + 1
+        if self.type in _SIMPLE_SENSORS:
+            return _SIMPLE_SENSORS[self.type][1]
+        raise ValueError("sensor type %r is not one the reference registers" % self.type)
 
 
 def _cstr(s):
@@ -92,8 +133,16 @@ def _write_sensor(f, s):
         f.write(struct.pack("<iiII4f2fii", s.frame_format, s.pixel_format, s.width, s.height, *s.intrinsics,
                             *s.disparity_params, s.disparity_type, s.distortion_type))
         f.write(struct.pack("<5f", *s.distortion[:5]))
-    elif s.type != GROUND_TRUTH:
-        raise ValueError("sensor type %r is not supported" % s.type)
+    elif s.type in _SIMPLE_SENSORS:
+        fmt = _SIMPLE_SENSORS[s.type][0]
+        if fmt:
+            n = len(struct.unpack(fmt, bytes(struct.calcsize(fmt))))
+            values = tuple(s.block) if s.block else (0,) * n
+            if s.type == EVENT_CAMERA and not s.block:
+                values = (s.width, s.height)
+            f.write(struct.pack(fmt, *values))
+    else:
+        raise ValueError("sensor type %r is not one the reference registers" % s.type)
 
 
 def write_slam(path, sensors, frames):
@@ -107,15 +156,17 @@ def write_slam(path, sensors, frames):
             _write_sensor(f, s)
         for ts, idx, payload in frames:
             payload = bytes(payload)
-            if len(payload) != sensors[idx].frame_size:
-                raise ValueError("frame of sensor %d has %d bytes, expected %d" % (idx, len(payload),
-                                                                                  sensors[idx].frame_size))
+            want = sensors[idx].frame_size
+            if want is not None and len(payload) != want:
+                raise ValueError("frame of sensor %d has %d bytes, expected %d" % (idx, len(payload), want))
             if isinstance(ts, tuple):                       # (seconds, nanoseconds), kept exactly
                 sec, nsec = ts
             else:
                 sec = int(ts)
                 nsec = int(round((ts - sec) * 1e9))
             f.write(struct.pack("<IIB", sec, nsec, idx))
+            if sensors[idx].variable_size:
+                f.write(struct.pack("<I", len(payload)))
             f.write(payload)
 
 
@@ -148,8 +199,14 @@ def _read_sensor(f):
         s.frame_format, s.pixel_format, s.width, s.height = v[:4]
         s.intrinsics, s.disparity_params, s.disparity_type, s.distortion_type = tuple(v[4:8]), tuple(v[8:10]), v[10], v[11]
         s.distortion = struct.unpack("<5f", _read_exact(f, 20)) + (0.0,) * 10
-    elif typ != GROUND_TRUTH:
-        raise ValueError("sensor %r has type %r, which this reader does not support" % (name, typ))
+    elif typ in _SIMPLE_SENSORS:
+        fmt = _SIMPLE_SENSORS[typ][0]
+        if fmt:
+            s.block = struct.unpack(fmt, _read_exact(f, struct.calcsize(fmt)))
+            if typ == EVENT_CAMERA:
+                s.width, s.height = s.block
+    else:
+        raise ValueError("sensor %r has type %r, which the reference does not register" % (name, typ))
     return s
 
 
@@ -173,7 +230,12 @@ def iter_frames(f, sensors):
         sec, nsec, idx = struct.unpack("<IIB", head)
         if idx >= len(sensors):
             raise ValueError("frame refers to sensor %d of %d" % (idx, len(sensors)))
-        yield sec + nsec * 1e-9, sensors[idx], _read_exact(f, sensors[idx].frame_size)
+        size = sensors[idx].frame_size
+        if sensors[idx].variable_size:
+            (counted,) = struct.unpack("<I", _read_exact(f, 4))
+            if size is None:
+                size = counted
+        yield sec + nsec * 1e-9, sensors[idx], _read_exact(f, size)
 
 
 def read_depth_sequence(path):

@@ -4,6 +4,8 @@ import os
 import re
 import subprocess
 
+import collections
+
 import numpy as np
 import pytest
 
@@ -216,12 +218,90 @@ def test_slam_reader_refuses_what_it_cannot_size(tmp_path):
     bad.write_bytes(b"SLAN\0" + bytes(8))
     with pytest.raises(ValueError, match="magic"):
         slamfile.read_slam_header(open(bad, "rb"))
-    imu = tmp_path / "imu.slam"
-    with open(imu, "wb") as f:
+    odd = tmp_path / "odd.slam"
+    with open(odd, "wb") as f:
         f.write(b"SLAM\0" + (1).to_bytes(4, "little") + (1).to_bytes(4, "little"))
-        f.write(bytes([4]) + b"IMU\0" + bytes([4]) + b"IMU\0" + bytes([0]) + (1).to_bytes(4, "little") + b"\0" + bytes(72))
-    with pytest.raises(ValueError, match="does not support"):
-        slamfile.read_slam_header(open(imu, "rb"))
+        f.write(bytes([6]) + b"Sonar\0" + bytes([6]) + b"Sonar\0" + bytes([0]) + (1).to_bytes(4, "little") + b"\0" + bytes(72))
+    with pytest.raises(ValueError, match="does not register"):
+        slamfile.read_slam_header(open(odd, "rb"))
+
+
+def _reference_shaped_slam(path, depth, ts, gt, intr, with_extras):
+    """A .slam file in the shape the reference's generators give their files: a TUM file's default sensors (RGB,
+    Grey, Depth, ground truth, Accelerometer: tools/dataset-tools/include/TUM.h:178-183) plus, with_extras, every
+    other sensor type the reference registers, with frames of all of them mixed into the stream."""
+    from slambench_amd import slamfile as sf
+    n, h, w = depth.shape
+    k = (intr[0] / w, intr[1] / h, intr[2] / w, intr[3] / h)
+    sensors = [sf.Sensor("GroundTruth", sf.GROUND_TRUTH, description="GroundTruthSensor"),
+               sf.Sensor("Grey", sf.CAMERA, rate=30, pixel_format=sf.PIXEL_FORMATS["G_I_8"], width=w, height=h, intrinsics=k),
+               sf.Sensor("RGB", sf.CAMERA, rate=30, pixel_format=sf.PIXEL_FORMATS["RGB_III_888"], width=w, height=h, intrinsics=k),
+               sf.Sensor("Depth", sf.DEPTH, rate=30, pixel_format=sf.PIXEL_FORMATS["D_I_16"], width=w, height=h, intrinsics=k,
+                         disparity_params=(0.001, 0.0))]
+    if with_extras:
+        sensors += [sf.Sensor("Accelerometer", sf.ACCELEROMETER, block=tuple(range(18))),
+                    sf.Sensor("PointCloud", sf.POINT_CLOUD, description="Ground truth point cloud"),
+                    sf.Sensor("Gyro", sf.GYRO), sf.Sensor("IMU", sf.IMU, block=(1.0,) * 8), sf.Sensor("Odom", sf.ODOM),
+                    sf.Sensor("Lidar", sf.LIDAR, block=(1e5, 1.7, -3.14, 3.14, -0.4, 0.3, 0.2, 0.4, 64)),
+                    sf.Sensor("Events", sf.EVENT_CAMERA, width=346, height=260)]
+    idx = {s.name: i for i, s in enumerate(sensors)}
+    rng = np.random.default_rng(5)
+
+    def frames():
+        if with_extras:                                     # the whole-scene cloud comes first (ICLNUIM.cpp:394-406)
+            pts = rng.normal(size=(1000, 3)).astype(np.float32)
+            yield 0.0, idx["PointCloud"], (1000).to_bytes(4, "little") + pts.tobytes()
+        for i in range(n):
+            t = float(ts[i])
+            yield t, idx["GroundTruth"], np.asarray(gt[i], np.float32).T.tobytes()
+            if with_extras:                                 # inertial sensors tick several times per image
+                for j in range(3):
+                    yield t + 0.003 * j, idx["Accelerometer"], rng.normal(size=3).astype(np.float32).tobytes()
+                yield t + 0.001, idx["Gyro"], bytes(12)
+                yield t + 0.001, idx["IMU"], bytes(24)
+                yield t + 0.002, idx["Odom"], bytes(52)
+                yield t + 0.002, idx["Lidar"], bytes(16 * (i + 1))
+                yield t + 0.002, idx["Events"], bytes(5)    # 346 x 260: two-byte coordinates
+            yield t, idx["Grey"], bytes(w * h)
+            yield t, idx["RGB"], bytes(3 * w * h)
+            yield t, idx["Depth"], depth[i].tobytes()
+
+    sf.write_slam(path, sensors, frames())
+    return sensors
+
+
+def test_slam_reader_steps_over_every_reference_sensor(tmp_path):
+    """Files as the reference writes them by default: the Accelerometer of its TUM generator, the PointCloud of its
+    ICL-NUIM generator, and the rest of its sensor database.  The depth stream read through them is the depth stream."""
+    from slambench_amd import slamfile
+    depth, gt, ts = synth.make_sequence(3, seed=3)
+    intr = (481.2, 480.0, 319.5, 239.5)
+    plain, full = str(tmp_path / "plain.slam"), str(tmp_path / "full.slam")
+    _reference_shaped_slam(plain, depth, ts, gt, intr, with_extras=False)
+    sensors = _reference_shaped_slam(full, depth, ts, gt, intr, with_extras=True)
+    a = slamfile.read_depth_sequence(plain)
+    b = slamfile.read_depth_sequence(full)
+    assert np.array_equal(a[1], b[1]) and np.array_equal(a[1], depth)
+    assert np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3]) and np.array_equal(a[4], b[4])
+    with open(full, "rb") as f:
+        back = slamfile.read_slam_header(f)
+        assert [s.type for s in back] == [s.type for s in sensors]
+        by_name = {s.name: s for s in back}
+        assert by_name["Accelerometer"].block == tuple(float(v) for v in range(18))
+        assert by_name["Lidar"].block[-1] == 64 and by_name["Events"].frame_size == 5
+        assert by_name["PointCloud"].variable_size and by_name["PointCloud"].is_ground_truth
+        assert not by_name["Accelerometer"].variable_size and by_name["Accelerometer"].frame_size == 12
+        kinds = collections.Counter(s.type for _, s, _ in slamfile.iter_frames(f, back))
+    assert kinds == {"PointCloud": 1, "GroundTruthTrajectory": 3, "Accelerometer": 9, "Gyro": 3, "IMU": 3, "Odom": 3,
+                     "Lidar": 3, "EventCamera": 3, "Camera": 6, "Depth": 3}
+    # byte-level check of one sensor block against the reference's layout: name, type, index, description, rate,
+    # pose, delay, then 12 + 3 + 3 floats (AccelerometerSensor.cpp:30-35)
+    raw = open(full, "rb").read()
+    at = raw.index(b"\x0eAccelerometer\0\x0eAccelerometer\0")
+    tail = raw[at + 30:]
+    assert tail[0] == 4 and tail[1:5] == (1).to_bytes(4, "little") and tail[5:6] == b"\0"
+    block = np.frombuffer(tail[6 + 4 + 64 + 4:6 + 4 + 64 + 4 + 72], np.float32)
+    assert np.array_equal(block, np.arange(18, dtype=np.float32))
 
 
 def test_rpe_definition():

@@ -159,3 +159,62 @@ def test_run_script_writes_a_complete_log(torch_cuda, tmp_path):
     assert cols[7] == "Duration_Frame" and cols[-3:] == ["X", "Y", "Z"] and rows.shape == (n, len(cols))
     assert props["volume-resolution"] == "128,128,128"
     assert rows[-1, cols.index("ATE_RMSE")] < 0.02
+
+
+def _reference_frame_loop(kinds, frame_limit, start_frame):
+    """The reference's frame loop reduced to its counter (framework/shared/src/SLAMBenchConfiguration.cpp:239-325):
+    `kinds` is the sensor type of every frame in file order; returns the indices (into the depth frames) of the
+    frame-sets a depth-only plugin processes."""
+    frame_count, depth_seen, processed = 0, 0, []
+    for kind in kinds:
+        frame_count += 1
+        is_depth = kind == "Depth"
+        depth_seen += is_depth
+        if kind == "GroundTruthTrajectory":
+            continue
+        if frame_count < start_frame * 3:
+            continue
+        if not is_depth:                      # update_frame says "not complete yet"
+            continue
+        processed.append(depth_seen - 1)
+        frame_count += 1
+        if frame_limit > 0 and frame_count >= frame_limit:
+            break
+    return processed
+
+
+def test_reference_written_files_and_reference_frame_counting(torch_cuda, tmp_path):
+    """A file with everything the reference's generators put into theirs (Accelerometer, PointCloud, ... frames mixed
+    into the stream) gives the trajectory of the plain file, and --reference-frame-limit makes -fl / -s select the
+    frame-sets the reference's own counter would."""
+    from slambench_amd import slamfile
+    from tests.test_host_cpu import _reference_shaped_slam
+    n = 12
+    intr = (481.2, 480.0, 319.5, 239.5)
+    depth, gt, ts = synth.make_sequence(n, seed=3, intrinsics=intr)
+    plain, full = str(tmp_path / "plain.slam"), str(tmp_path / "full.slam")
+    _reference_shaped_slam(plain, depth, ts, gt, intr, with_extras=False)
+    _reference_shaped_slam(full, depth, ts, gt, intr, with_extras=True)
+    args = ["-c", "4", "-v", "128,128,128"]
+    a = harness.run_mini_harness(plain, args)
+    b = harness.run_mini_harness(full, args)
+    assert a.returncode == 0 and b.returncode == 0, (a.stderr, b.stderr)
+    ra, rb = harness.parse_log(a.stdout)[2], harness.parse_log(b.stdout)[2]
+    assert ra.shape == rb.shape == (n, 11)
+    assert np.array_equal(ra[:, -3:], rb[:, -3:]) and np.array_equal(ra[:, 1], rb[:, 1])
+    assert np.abs(ra[-1, -3:] - 4.0).max() > 1e-3                      # and the camera did move
+    for path in (plain, full):
+        with open(path, "rb") as f:
+            kinds = [s.type for _, s, _ in slamfile.iter_frames(f, slamfile.read_slam_header(f))]
+        for fl, start in ((30, 0), (0, 2), (40, 3)):
+            want = _reference_frame_loop(kinds, fl, start)
+            assert 0 < len(want) < n or fl == 0
+            r = harness.run_mini_harness(path, args + ["--reference-frame-limit", "-s", str(start)], frame_limit=fl)
+            assert r.returncode == 0, r.stderr
+            rows = harness.parse_log(r.stdout)[2]
+            assert rows.shape[0] == len(want), (path, fl, start, rows.shape[0], len(want))
+            np.testing.assert_allclose(rows[:, 1], ts[want], atol=1e-8)
+    # the plain counting: -s 2 -fl 3 processes frame-sets 2, 3 and 4
+    r = harness.run_mini_harness(full, args + ["-s", "2"], frame_limit=3)
+    assert r.returncode == 0, r.stderr
+    np.testing.assert_allclose(harness.parse_log(r.stdout)[2][:, 1], ts[2:5], atol=1e-8)
