@@ -626,13 +626,14 @@ __device__ Mat4 se3_exp(const double mu[6]) {
             // |theta| < 0.5 rad: the Taylor series of sin(t)/t, (1-cos t)/t^2 and (t-sin t)/t^3 in t^2
             // converge below 1e-15 in eight terms; the pose is rounded to float afterwards.  This replaces
             // a double-precision sin/cos/sqrt chain on the critical path of every ICP iteration.
+            // (evaluated with fused multiply-adds: half the length of the dependent chain, and closer to the sum)
             const double t2 = theta_sq;
-            A = 1.0 + t2 * (-1.0 / 6 + t2 * (1.0 / 120 + t2 * (-1.0 / 5040 + t2 * (1.0 / 362880 +
-                t2 * (-1.0 / 39916800 + t2 * (1.0 / 6227020800.0 + t2 * (-1.0 / 1307674368000.0)))))));
-            B = 0.5 + t2 * (-1.0 / 24 + t2 * (1.0 / 720 + t2 * (-1.0 / 40320 + t2 * (1.0 / 3628800 +
-                t2 * (-1.0 / 479001600 + t2 * (1.0 / 87178291200.0 + t2 * (-1.0 / 20922789888000.0)))))));
-            C = 1.0 / 6 + t2 * (-1.0 / 120 + t2 * (1.0 / 5040 + t2 * (-1.0 / 362880 + t2 * (1.0 / 39916800 +
-                t2 * (-1.0 / 6227020800.0 + t2 * (1.0 / 1307674368000.0 + t2 * (-1.0 / 355687428096000.0)))))));
+            A = fma(t2, fma(t2, fma(t2, fma(t2, fma(t2, fma(t2, fma(t2, -1.0 / 1307674368000.0, 1.0 / 6227020800.0),
+                -1.0 / 39916800), 1.0 / 362880), -1.0 / 5040), 1.0 / 120), -1.0 / 6), 1.0);
+            B = fma(t2, fma(t2, fma(t2, fma(t2, fma(t2, fma(t2, fma(t2, -1.0 / 20922789888000.0, 1.0 / 87178291200.0),
+                -1.0 / 479001600), 1.0 / 3628800), -1.0 / 40320), 1.0 / 720), -1.0 / 24), 0.5);
+            C = fma(t2, fma(t2, fma(t2, fma(t2, fma(t2, fma(t2, fma(t2, -1.0 / 355687428096000.0, 1.0 / 1307674368000.0),
+                -1.0 / 6227020800.0), 1.0 / 39916800), -1.0 / 362880), 1.0 / 5040), -1.0 / 120), 1.0 / 6);
         } else {
             const double theta = sqrt(theta_sq);
             const double inv_theta = 1.0 / theta;
@@ -662,12 +663,33 @@ __device__ Mat4 se3_exp(const double mu[6]) {
     return out;
 }
 
+// delta * pose for a delta whose last row is (0, 0, 0, 1) (what se3_exp returns), entry by entry in mat_mul's order
+// of operations.  When the pose's last row is (0, 0, 0, 1) as well, so is the product's: its entries are sums of
+// 0 * p + ... + 1 * p33 over finite p, and the twelve other entries are all that is computed.
+__device__ inline Mat4 pose_product(const Mat4 &D, const Mat4 &P) {
+    const bool affine = P.m[12] == 0.f && P.m[13] == 0.f && P.m[14] == 0.f && P.m[15] == 1.f;     // wave-uniform
+    if (!affine) return mat_mul(D, P);
+    Mat4 R;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float s = D.m[i * 4 + 0] * P.m[0 * 4 + j];
+            s = s + D.m[i * 4 + 1] * P.m[1 * 4 + j];
+            s = s + D.m[i * 4 + 2] * P.m[2 * 4 + j];
+            s = s + D.m[i * 4 + 3] * P.m[3 * 4 + j];
+            R.m[i * 4 + j] = s;
+        }
+    R.m[12] = 0.f; R.m[13] = 0.f; R.m[14] = 0.f; R.m[15] = 1.f;
+    return R;
+}
+
 // pose <- exp(x) * pose ; returns |x| < threshold.  Wave-cooperative: all 64 lanes call it and all get
 // the same pose, x and result.
 __device__ bool update_pose_wave(Mat4 &pose, const float *sums, float icp_threshold, double x[6], int *used_jacobi) {
     solve_normal_equations_wave(sums + 1, x, used_jacobi);
     const Mat4 delta = se3_exp(x);
-    pose = mat_mul(delta, pose);
+    pose = pose_product(delta, pose);
     double n2 = 0.0;
     for (int i = 0; i < 6; ++i) n2 += x[i] * x[i];
     return n2 < (double)icp_threshold * (double)icp_threshold;   // |x| < threshold
@@ -1448,7 +1470,7 @@ hipError_t launch_update_pose(float *pose16, double *x6, int *converged, const f
 
 // Diagnostic: n dependent pose updates by one wavefront (each update perturbs the sums of the next), to time
 // the solve + exponential + pose product chain without launch effects.
-__global__ void k_update_pose_chain(float *pose16, const float *sums, float thr, int n) {
+__global__ __launch_bounds__(64) void k_update_pose_chain(float *pose16, const float *sums, float thr, int n) {
     __shared__ float s[32];
     Mat4 pose;
     for (int i = 0; i < 16; ++i) pose.m[i] = pose16[i];
