@@ -91,6 +91,9 @@ typedef struct kfh_frame_status {
     float   sums[32];     /* last ICP reduction (layout of reduceKernel)        */
     int32_t icp_iterations; /* ICP iterations executed in this frame (all levels) */
     int32_t slow_solves;    /* of those, solves that needed the eigen-decomposition path */
+    int32_t examined_solves; /* of those, solves whose conditioning was too close to the reference's 1e6 cut-off to
+                               certify cheaply: the smallest singular value was computed (eigen-decompositions included) */
+    int32_t reserved_;
 } kfh_frame_status;
 
 typedef struct kfh_context kfh_context;

@@ -468,16 +468,18 @@ __device__ inline void matvec6_wave(double m_elem, const double u[6], double y[6
 }
 
 // Power iteration: dominant eigenpair of the symmetric positive definite 6x6 matrix held one element per
-// lane.  Runs in rounds of 8 products until the residual |M u - theta u| / |theta u| drops below 1e-12;
-// gives up (returns false) after 12 rounds, which happens when the two largest eigenvalues nearly coincide.
+// lane.  Runs in rounds of 2 * PAIRS products until the residual |M u - theta u| / |theta u| drops below 1e-12
+// (the eigenvalue is then good to 1e-24 relative, the eigenvector to 1e-12); gives up (returns false) after 96
+// products, which happens when the two largest eigenvalues nearly coincide.
+template <int PAIRS>
 __device__ inline bool dominant_eigenpair_wave(double m_elem, double &theta, double u[6]) {
 #pragma unroll
     for (int k = 0; k < 6; ++k) u[k] = 1.0 + 0.0625 * k;      // generic start
 #pragma unroll 1
-    for (int round = 0; round < 12; ++round) {
+    for (int round = 0; round < 48 / PAIRS; ++round) {
         double y[6];
 #pragma unroll 1
-        for (int it = 0; it < 4; ++it) {
+        for (int it = 0; it < PAIRS; ++it) {
             matvec6_wave(m_elem, u, y);
             matvec6_wave(m_elem, y, u);
         }
@@ -517,18 +519,55 @@ __device__ inline bool truncate_smallest_wave(double c_elem, double inv_elem, co
     const int lane = threadIdx.x & 63;
     const int i = lane >> 3, j = lane & 7;
     const bool in_c = i < 6 && j < 6;
-    double lam_max, mu, ubig[6], v[6];
-    if (!dominant_eigenpair_wave(c_elem, lam_max, ubig)) return false;
-    if (!dominant_eigenpair_wave(in_c ? inv_elem : 0.0, mu, v)) return false;
-    if (!(mu > 0.0) || !(lam_max > 0.0)) return false;
-    // second smallest eigenvalue of C: 1 / lambda_max(C^-1 - mu v v^T) >= 1 / ||C^-1 - mu v v^T||_F
+    double mu, v[6];
+    // (rounds of 8 products: the iteration on C^-1 typically needs 6, and a round of 4 would fall just short)
+    if (!dominant_eigenpair_wave<4>(in_c ? inv_elem : 0.0, mu, v)) return false;
+    if (!(mu > 0.0)) return false;
+    const double lam_min = 1.0 / mu;
+    // lambda_max of C is only needed for the comparison lambda_min * 1e6 > lambda_max: any Rayleigh quotient bounds
+    // it from below and the Frobenius norm from above, and four products from a generic start bring the quotient
+    // within a fraction of a percent.  Only when lambda_min * 1e6 falls between the two bounds is the eigenvalue
+    // itself computed (power iteration to convergence).
+    const double fro_c = sqrt(wave_sum_f64(c_elem * c_elem));
+    if (!(fro_c > 0.0) || !(fro_c < 1e150)) return false;
+    double u[6], y[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) u[k] = 1.0 + 0.0625 * k;      // generic start
+    const double unit = 1.0 / fro_c;                          // keeps the iterates in range: |C / fro_c| <= 1
+#pragma unroll 1
+    for (int it = 0; it < 2; ++it) {
+        matvec6_wave(c_elem, u, y);
+        matvec6_wave(c_elem, y, u);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) u[k] *= unit * unit;
+    }
+    matvec6_wave(c_elem, u, y);
+    double uu = 0.0, uy = 0.0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) { uu += u[k] * u[k]; uy += u[k] * y[k]; }
+    if (!(uu > 0.0)) return false;
+    const double below = (uy / uu) * (1.0 - 1e-12), above = fro_c * (1.0 + 1e-12);
+    double lam_upper = above;
+    bool keep_min;                                            // the reference's rule for the smallest singular value
+    if (lam_min * 1e6 > above) {
+        keep_min = true;
+    } else if (lam_min * 1e6 < below) {
+        keep_min = false;
+    } else {
+        double lam_max, ubig[6];
+        if (!dominant_eigenpair_wave<4>(c_elem, lam_max, ubig)) return false;
+        if (!(lam_max > 0.0)) return false;
+        keep_min = lam_min * 1e6 > lam_max;
+        lam_upper = lam_max;
+    }
+    // second smallest eigenvalue of C: 1 / lambda_max(C^-1 - mu v v^T) >= 1 / ||C^-1 - mu v v^T||_F; it must clearly be
+    // kept (an upper bound of lambda_max makes the test stricter, never laxer)
     double vi = 0.0, vj = 0.0;
 #pragma unroll
     for (int k = 0; k < 6; ++k) { vi = (i == k) ? v[k] : vi; vj = (j == k) ? v[k] : vj; }
     const double d = in_c ? inv_elem - mu * vi * vj : 0.0;
     const double fro2 = wave_sum_f64(d * d);
-    if (!(lam_max * lam_max * fro2 < 0.96e12)) return false;      // second eigenvalue not clearly kept
-    const bool keep_min = (1.0 / mu) * 1e6 > lam_max;             // the reference's rule for the smallest
+    if (!(lam_upper * lam_upper * fro2 < 0.96e12)) return false;      // second eigenvalue not clearly kept
     double vb = 0.0;
 #pragma unroll
     for (int k = 0; k < 6; ++k) vb += v[k] * b[k];
@@ -746,7 +785,9 @@ __device__ void finish_tracking(const FinishArgs &a, bool ran_tracking, int iter
         for (int i = 0; i < 16; ++i) st->pose[i] = c->pose.m[i];
         for (int i = 0; i < 32; ++i) st->sums[i] = c->sums[i];
         st->icp_iterations = iterations;
-        st->slow_solves = slow_solves;
+        st->slow_solves = slow_solves & 0xFFFF;
+        st->examined_solves = slow_solves >> 16;
+        st->reserved_ = 0;
     }
 }
 
@@ -807,7 +848,8 @@ __device__ inline void icp_finalize_wave0(const IcpState *__restrict__ in, Mat4 
             const bool level_finished = converged || in_last != 0;
             *done_mask_lds = in_done_mask | (level_finished ? (1 << in_level) : 0);
             *iterations_lds = in_iterations + 1;
-            *slow_lds = in_slow + (slow == 1 ? 1 : 0);
+            // low half: full eigen-decompositions; high half: solves that had to examine the smallest singular value
+            *slow_lds = in_slow + (slow == 1 ? 1 : 0) + (slow != 0 ? 0x10000 : 0);
         }
     } else {
         if (lane < 32) sums_lds[lane] = in->sums[lane];
@@ -1335,7 +1377,9 @@ __device__ inline void finish_tracking_wave(const FinishArgs &a, Mat4 pose, cons
         status_img[KFH_STATUS_DW(raycasted)] = (unsigned)a.will_raycast;
         put_mat(status_img, KFH_STATUS_DW(pose), pose);
         status_img[KFH_STATUS_DW(icp_iterations)] = (unsigned)iterations;
-        status_img[KFH_STATUS_DW(slow_solves)] = (unsigned)slow_solves;
+        status_img[KFH_STATUS_DW(slow_solves)] = (unsigned)slow_solves & 0xFFFFu;
+        status_img[KFH_STATUS_DW(examined_solves)] = (unsigned)slow_solves >> 16;
+        status_img[KFH_STATUS_DW(reserved_)] = 0u;
     }
     if (lane < 32) {
         const unsigned v = __builtin_bit_cast(unsigned, sums_lds[lane]);

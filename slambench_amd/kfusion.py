@@ -116,6 +116,7 @@ class KFusion:
             "pose": np.array(st.pose, np.float32).reshape(4, 4),
             "sums": np.array(st.sums, np.float32),
             "icp_iterations": st.icp_iterations, "slow_solves": st.slow_solves,
+            "examined_solves": st.examined_solves,
         }
 
     def integrate_totals(self):

@@ -41,7 +41,8 @@ ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p)
 class FrameStatus(C.Structure):
     _fields_ = [("frame", C.c_int32), ("tracked", C.c_int32), ("integrated", C.c_int32),
                 ("raycasted", C.c_int32), ("pose", C.c_float * 16), ("sums", C.c_float * 32),
-                ("icp_iterations", C.c_int32), ("slow_solves", C.c_int32)]
+                ("icp_iterations", C.c_int32), ("slow_solves", C.c_int32),
+                ("examined_solves", C.c_int32), ("reserved_", C.c_int32)]
 
 
 class KfhError(RuntimeError):

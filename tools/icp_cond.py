@@ -13,7 +13,7 @@ period = list(range(len(depth))) + list(range(len(depth) - 2, 0, -1))
 kf = KFusion(cfg)
 for i in range(n):
     kf.process_frame(depth[period[i % len(period)]])
-conds, fro, slow, its = [], [], [], []
+conds, fro, slow, its, exam = [], [], [], [], []
 for f in range(4, n):
     st = kf.status(f)
     s = np.asarray(st["sums"], np.float64)
@@ -28,9 +28,11 @@ for f in range(4, n):
     fro.append(np.linalg.norm(C) * np.linalg.norm(np.linalg.inv(C)))
     slow.append(st["slow_solves"])
     its.append(st["icp_iterations"])
+    exam.append(st["examined_solves"])
 conds, fro = np.array(conds), np.array(fro)
 print("cond_2 percentiles 5/25/50/75/95/max: ", np.percentile(conds, [5, 25, 50, 75, 95, 100]))
 print("fro product percentiles 5/25/50/75/95/max:", np.percentile(fro, [5, 25, 50, 75, 95, 100]))
 print("frames with cond_2 > 1e6: %d of %d; with fro product > 0.98e6: %d" % ((conds > 1e6).sum(), len(conds), (fro > 0.98e6).sum()))
 print("slow solves per frame: mean %.2f max %d; iterations mean %.1f" % (np.mean(slow), np.max(slow), np.mean(its)))
+print("solves per frame that had to examine the smallest singular value: mean %.2f max %d" % (np.mean(exam), np.max(exam)))
 print("eigenvalues of the last frame:", w)
