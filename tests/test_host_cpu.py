@@ -39,7 +39,7 @@ def test_config_struct_layout_matches_header():
     assert C.sizeof(KfhConfig) == 4 * (3 + 5 + 9 + 2 + 3 + 2 + 1 + 2)
     from oracle import kf_ref
     assert [f[0] for f in KfhConfig._fields_] == [f[0] for f in kf_ref.Config._fields_]
-    assert C.sizeof(native.FrameStatus) == 4 * (4 + 16 + 32 + 2)
+    assert C.sizeof(native.FrameStatus) == 4 * (4 + 16 + 32 + 4)      # ..., iterations, slow, examined, reserved
 
 
 def test_invalid_arguments_are_rejected_before_any_device_work():
