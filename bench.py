@@ -70,6 +70,8 @@ def parse_args():
     ap.add_argument("--force-exchange", action="store_true",
                     help="--mode zslab on ONE rank: still take the exchange path (slab march, all-gather, composite, "
                          "all-reduce) through a single-rank RCCL group, to time the collectives' fixed cost")
+    ap.add_argument("--dense-traffic-json", default=os.path.join(ROOT, "profiles", "r2_dense_integrate.json"),
+                    help="counter bytes of the dense integration leg (tools/make_profiles.py --dense)")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "integrate_traffic.json"),
                     help="HBM bytes per integrate launch from the committed rocprofv3 PMC passes")
     return ap.parse_args()
@@ -412,6 +414,18 @@ def main():
         }
         if not a.no_dense_leg and not zslab and world == 1:
             result["roofline_dense"] = dense_integrate_leg(KFusion, KFusionConfig, TUM_FR1_DEPTH_INTRINSICS, V, torch)
+            dense = result["roofline_dense"]
+            if os.path.exists(a.dense_traffic_json):
+                try:
+                    with open(a.dense_traffic_json) as f:
+                        dj = json.load(f)
+                    if int(dj.get("volume", 0)) == V:
+                        dense["traffic"] = dj.get("hbm_bytes_per_launch")
+                        dense["traffic_source"] = ("profiles/%s: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
+                                                   "tools/dense_leg.py (the same leg as a program of its own); not "
+                                                   "measured in this run" % os.path.basename(a.dense_traffic_json))
+                except Exception:
+                    pass
         if not a.no_cpu_baseline and a.cpu_frames > 0 and world == 1:
             threads = max(1, min(a.cpu_threads, os.cpu_count() or 1))
             n_cpu = min(a.cpu_frames, n_unique)

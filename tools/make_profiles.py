@@ -51,7 +51,39 @@ def pmc_means(d, skip=4):
     return res
 
 
+def dense(tag, base, volume=512):
+    """profiles/TAG_dense_*: kernel summary of tools/dense_leg.py under the profiler and the counter bytes of its
+    k_integrate launches next to the 8 B x V^3 they must move."""
+    prof = os.path.join(ROOT, "profiles")
+    stats_csv, text = kernel_summary(os.path.join(base, "dense_kt"), 16)
+    with open(os.path.join(prof, tag + "_dense_kernel_summary.txt"), "w") as f:
+        f.write(text)
+    pmc = {}
+    for d in (os.path.join(base, "dense_fetch"), os.path.join(base, "dense_write")):
+        for k, cs in pmc_means(d).items():
+            pmc.setdefault(k, {}).update(cs)
+    name = sorted(k for k in pmc if k.startswith("k_integrate") and "plan" not in k)[-1]
+    ki = pmc[name]
+    fetch_kib, write_kib = ki["FETCH_SIZE"]["mean"], ki["WRITE_SIZE"]["mean"]
+    with open(os.path.join(base, "dense_under_trace.json")) as f:
+        leg = json.loads(f.read().strip().splitlines()[-1])
+    out = {
+        "volume": volume, "kernel": name, "leg_under_kernel_trace": leg,
+        "FETCH_SIZE_KiB_per_launch": fetch_kib, "WRITE_SIZE_KiB_per_launch": write_kib,
+        "correction": "bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950: FETCH_SIZE under-counts 128 B requests by half)",
+        "hbm_bytes_per_launch": (2.0 * fetch_kib + write_kib) * 1024.0,
+        "algorithmic_bytes_per_launch": 8.0 * volume ** 3,
+    }
+    out["traffic_over_algorithmic"] = out["hbm_bytes_per_launch"] / out["algorithmic_bytes_per_launch"]
+    with open(os.path.join(prof, tag + "_dense_integrate.json"), "w") as f:
+        json.dump(out, f, indent=1)
+    print(text)
+    print(json.dumps({k: v for k, v in out.items() if k != "leg_under_kernel_trace"}, indent=1))
+
+
 def main():
+    if sys.argv[1] == "--dense":
+        return dense(sys.argv[2], sys.argv[3], int(sys.argv[4]) if len(sys.argv) > 4 else 512)
     tag, frames, kt, fd, wd = sys.argv[1], int(sys.argv[2]), sys.argv[3], sys.argv[4], sys.argv[5]
     volume = int(sys.argv[6]) if len(sys.argv) > 6 else 512
     prof = os.path.join(ROOT, "profiles")
