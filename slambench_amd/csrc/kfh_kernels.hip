@@ -1707,6 +1707,9 @@ constexpr int KFH_PLAN_COARSE_CELLS = KFH_PLAN_MAX_TILES / 16 + 64;
 // decides: the smallest power of two that brings the expected number of items down to target_items.
 __device__ inline int integrate_group_size(const IntegrateArgs &a) {
     const unsigned last = a.totals ? (unsigned)a.totals[3] : 0u;     // only the work launch writes it: stable here
+    // at least half of the volume was visited: the longest runs leave nothing to replay and still make more items
+    // than the device has wavefront slots to fill
+    if (last >= (unsigned)(a.gx * a.gy) * (unsigned)a.gz / 2u) return 32;
     int g = a.min_group;
     while (g < 32 && last / (unsigned)g > (unsigned)a.target_items) g <<= 1;
     return g;
