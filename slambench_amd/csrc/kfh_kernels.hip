@@ -2004,8 +2004,9 @@ void set_integrate_debug(unsigned long long *d_buffer) { g_integrate_debug = d_b
 static int integrate_zchunk(int z1) {
     static const int forced = std::getenv("KFH_INTEGRATE_ZCHUNK") ? std::atoi(std::getenv("KFH_INTEGRATE_ZCHUNK")) : 0;
     if (forced >= INTEGRATE_UNROLL && forced % INTEGRATE_UNROLL == 0) return forced;
-    // measured per integration at 512^3: 16 -> 35 us, 32 -> 40 us, 64 -> 54 us; at 1024^3: 16 -> 126 us, 32 -> 104 us, 64 -> 107 us
-    return z1 <= 512 ? 16 : z1 <= 1024 ? 32 : 64;
+    // measured per integration at 512^3: 16 -> 35 us, 32 -> 40 us, 64 -> 54 us; at 1024^3: 16 -> 121 us, 32 -> 102 us,
+    // 64 -> 107 us; at 2048^3 (items of 256 planes): 64 -> 428 us, 32 -> 399 us (finer boxes are culled better)
+    return z1 <= 512 ? 16 : 32;
 }
 
 // Smallest number of boxes per work item (a power of two up to 32; the plan launch raises it when the previous
@@ -2015,7 +2016,7 @@ static int integrate_zchunk(int z1) {
 static int integrate_min_group(int z1) {
     static const int forced = std::getenv("KFH_INTEGRATE_GROUP") ? std::atoi(std::getenv("KFH_INTEGRATE_GROUP")) : 0;
     if (forced >= 1 && forced <= 32 && (forced & (forced - 1)) == 0) return forced;
-    return z1 <= 1024 ? 1 : 4;
+    return z1 <= 1024 ? 1 : 8;
 }
 static int integrate_target_items() {
     static const int forced = std::getenv("KFH_INTEGRATE_TARGET_ITEMS") ? std::atoi(std::getenv("KFH_INTEGRATE_TARGET_ITEMS")) : 0;
@@ -2026,7 +2027,9 @@ int integrate_box_voxels(int z1) { return 64 * 4 * integrate_zchunk(z1); }
 
 size_t integrate_box_list_bytes(const int res[3], int z1) {
     const int zchunk = integrate_zchunk(z1);
-    return (size_t)((res[0] + 63) / 64) * ((res[1] + 3) / 4) * ((z1 + zchunk - 1) / zchunk) * sizeof(uint2);
+    // an item holds at least min_group boxes' worth of z range
+    const int g = integrate_min_group(z1);
+    return (size_t)((res[0] + 63) / 64) * ((res[1] + 3) / 4) * (((z1 + zchunk - 1) / zchunk + g - 1) / g) * sizeof(uint2);
 }
 
 hipError_t launch_integrate(short2 *vol, const int res[3], const float dim[3], int z0, int z1,
@@ -2082,7 +2085,8 @@ hipError_t launch_fill_volume(short2 *vol, size_t nvox, hipStream_t s) {
 // owned slab in the sharded mode).
 // =====================================================================================================
 constexpr int RAY_BATCH = 4;        // steps one lane keeps in flight for its own ray
-constexpr int RAY_MAX_ROUNDS = 10;  // first pass: at most 40 samples per ray (the median ray needs about 32)
+constexpr int RAY_MAX_ROUNDS = 10;  // first pass: at most 40 samples per ray (the median ray needs about 32); 14 rounds for
+                                    //   volumes beyond 1024 voxels per side, whose fine step is shorter
 constexpr int RAY_FEW = 8;          // first pass ends for a wavefront with at most this many live rays
 constexpr int RAY_TAIL_BLOCKS = 1024;
 
@@ -2671,7 +2675,11 @@ static hipError_t launch_raycast_t(float4 *vertex, float4 *normal, float *ray_t,
     }
     const dim3 grid((w + 15) / 16, (h + 15) / 16);
     // tuning knobs for experiments (defaults: RAY_MAX_ROUNDS, 32 lanes per unfinished ray)
-    static const int max_rounds = std::getenv("KFH_RAY_ROUNDS") ? std::atoi(std::getenv("KFH_RAY_ROUNDS")) : RAY_MAX_ROUNDS;
+    // measured, frames/s: 1024^3 with 10 / 14 / 20 / 28 rounds 4302 / 4228 / 4100 / 3892; 2048^3 with 10 / 14 / 20 / 28
+    // rounds 2071 / 2302 / 2259 / 2196
+    static const int forced_rounds = std::getenv("KFH_RAY_ROUNDS") ? std::atoi(std::getenv("KFH_RAY_ROUNDS")) : 0;
+    const int res_max = res[0] > res[1] ? (res[0] > res[2] ? res[0] : res[2]) : (res[1] > res[2] ? res[1] : res[2]);
+    const int max_rounds = forced_rounds > 0 ? forced_rounds : (res_max > 1024 ? 14 : RAY_MAX_ROUNDS);
     static const int few = std::getenv("KFH_RAY_FEW") ? std::atoi(std::getenv("KFH_RAY_FEW")) : RAY_FEW;
     static const int tail_lanes = std::getenv("KFH_RAY_TAIL_LANES") ? std::atoi(std::getenv("KFH_RAY_TAIL_LANES")) : 32;
     if (part != RAYCAST_TAIL)
