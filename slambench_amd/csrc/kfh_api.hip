@@ -112,6 +112,13 @@ struct kfh_context {
     size_t partials_stride = 0;            // floats per buffer
     Ctrl *d_ctrl = nullptr;
     kfh_frame_status *d_status = nullptr;
+    // Pose record in host memory the finish launch writes for callers that ask for the pose after every frame
+    // (see PoseMail).  Written only while such a caller is there: the frame after a kfh_get_pose gets one.
+    PoseMail *h_mail = nullptr;
+    unsigned *d_mail = nullptr;            // the same record as the device addresses it
+    unsigned mail_seq = 0;                 // number of the last finish launch that was given the record
+    bool mail_current = false;             // that launch is the last finish launch queued, and no pose was set since
+    bool pose_read_this_frame = false, pose_read_last_frame = false;
     unsigned long long *d_stamps = nullptr; // diagnostic ICP time stamps (KFH_ICP_STAMPS=1), [launch][block][slot]
     // GUI images: allocated when first asked for
     signed char *d_track_codes = nullptr;  // trackKernel result code per pixel of the compute size
@@ -176,6 +183,7 @@ void free_all(kfh_context *c) {
         if (c->h_depth_pinned[i]) (void)hipHostFree(c->h_depth_pinned[i]);
         if (c->ev_slot_free[i]) (void)hipEventDestroy(c->ev_slot_free[i]);
     }
+    if (c->h_mail) (void)hipHostFree(c->h_mail);
     void *bufs[] = {c->set_tile_max[0], c->set_tile_max[1], c->d_depth_in[0], c->d_depth_in[1], c->set_float_depth[0], c->set_float_depth[1], c->set_scaled[0][0],
                     c->set_scaled[0][1], c->set_scaled[0][2], c->set_scaled[1][0], c->set_scaled[1][1],
                     c->set_scaled[1][2],
@@ -242,6 +250,8 @@ int init_state(kfh_context *c) {
     KFH_HIP(hipStreamSynchronize(c->stream));   // `init` lives on this stack frame
     KFH_HIP(launch_pose_derive(c->d_ctrl, c->k, 1, c->stream));
     c->box_list_fresh = c->ray_list_fresh = true;
+    c->mail_current = false;
+    c->pose_read_this_frame = c->pose_read_last_frame = false;
     c->frame = 0;
     c->d_depth_cur = c->d_depth_in[0];
     c->upload_slot = 0;
@@ -267,6 +277,17 @@ FinishArgs finish_args(const kfh_context *c, int seq, int pending_rows) {
     a.integration_rate = c->cfg.integration_rate;
     a.status_ring = c->d_status;
     return a;
+}
+
+// The finish launch of this frame writes the host-visible pose record when the caller read the pose during the
+// previous frame (one that does so every frame is served from the record from its second frame on).
+void attach_mail(kfh_context *c, FinishArgs *f) {
+    c->mail_current = false;
+    if (c->d_mail && c->pose_read_last_frame) {
+        f->mail = c->d_mail;
+        f->mail_seq = ++c->mail_seq;
+        c->mail_current = true;
+    }
 }
 
 }  // namespace
@@ -357,6 +378,20 @@ int kfh_create(const kfh_config *cfg, kfh_context **out) {
     if (e == hipSuccess) e = dev_alloc(&c->d_partials, 2 * c->partials_stride);
     if (e == hipSuccess) e = dev_alloc(&c->d_ctrl, 1);
     if (e == hipSuccess) e = dev_alloc(&c->d_status, KFH_STATUS_RING);
+    if (e == hipSuccess && !std::getenv("KFH_NO_POSE_MAIL")) {
+        // optional: without it kfh_get_pose copies the pose from device memory as before
+        void *h = nullptr, *d = nullptr;
+        if (hipHostMalloc(&h, sizeof(PoseMail), hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess) {
+            if (hipHostGetDevicePointer(&d, h, 0) == hipSuccess) {
+                std::memset(h, 0, sizeof(PoseMail));
+                c->h_mail = static_cast<PoseMail *>(h);
+                c->d_mail = static_cast<unsigned *>(d);
+            } else {
+                (void)hipHostFree(h);
+            }
+        }
+        (void)hipGetLastError();
+    }
     if (e == hipSuccess && std::getenv("KFH_ICP_STAMPS")) {
         const size_t n = (size_t)KFH_STAMP_LAUNCHES * KFH_STAMP_BLOCKS * KFH_STAMP_SLOTS;
         e = dev_alloc(&c->d_stamps, n);
@@ -476,7 +511,9 @@ static int track_impl(kfh_context *c, int share, int share_count, kfh_allreduce_
     int total_iterations = 0;
     for (int l = 0; l < 3; ++l) total_iterations += c->cfg.pyramid[l];
     if (c->frame % c->cfg.tracking_rate != 0 || total_iterations == 0) {
-        KFH_HIP(launch_track_skip(finish_args(c, 0, 0), c->stream));
+        FinishArgs f = finish_args(c, 0, 0);
+        attach_mail(c, &f);
+        KFH_HIP(launch_track_skip(f, c->stream));
     } else {
         // depth2vertex / vertex2normal are evaluated inside the iteration kernel from the depth pyramid;
         // the vertex / normal maps themselves are only materialised when a caller asks for them
@@ -536,6 +573,7 @@ static int track_impl(kfh_context *c, int share, int share_count, kfh_allreduce_
         }
         FinishArgs f = finish_args(c, seq, rows);
         if (sharded) f.partials_in = pending;
+        attach_mail(c, &f);
         KFH_HIP(launch_icp_finish(f, c->stream));
     }
     c->box_list_fresh = c->ray_list_fresh = true;      // both finish kernels empty the lists and set the raycast matrices
@@ -764,6 +802,8 @@ int kfh_end_frame(kfh_context *c) {
     // this frame is done with its depth images: only the side stream of the overlap mode ever waits for that (an
     // event record occupies the stream for a few microseconds, so it is not made for nothing)
     if (c->overlap) KFH_HIP(hipEventRecord(c->ev_set_free[c->cur_set], c->stream));
+    c->pose_read_last_frame = c->pose_read_this_frame;
+    c->pose_read_this_frame = false;
     c->frame++;
     return KFH_OK;
 }
@@ -791,6 +831,15 @@ int kfh_get_pose(kfh_context *c, float pose[16]) {
     KFH_REQUIRE(c != nullptr && pose != nullptr, "NULL argument");
     DeviceScope on_device(c->device);
     // the pose and the status record are final once tracking has finished: a postponed raycast pass may stay postponed
+    c->pose_read_this_frame = true;
+    if (c->mail_current) {
+        // the last finish launch left the pose in host memory: wait for the queued work as before, then read it there
+        KFH_HIP(hipStreamSynchronize(c->stream));
+        if (__atomic_load_n(&c->h_mail->seq, __ATOMIC_ACQUIRE) == c->mail_seq) {
+            std::memcpy(pose, c->h_mail->pose, sizeof(Mat4));
+            return KFH_OK;
+        }
+    }
     KFH_HIP(hipMemcpyAsync(pose, &c->d_ctrl->pose, sizeof(Mat4), hipMemcpyDeviceToHost, c->stream));
     KFH_HIP(hipStreamSynchronize(c->stream));
     return KFH_OK;
@@ -802,6 +851,7 @@ int kfh_set_pose(kfh_context *c, const float pose[16]) {
     if (int rc = flush_tail(c)) return rc;
     KFH_HIP(hipMemcpyAsync(&c->d_ctrl->pose, pose, sizeof(Mat4), hipMemcpyHostToDevice, c->stream));
     KFH_HIP(hipStreamSynchronize(c->stream));
+    c->mail_current = false;       // the record in host memory is the tracked pose, not this one
     KFH_HIP(launch_pose_derive(c->d_ctrl, c->k, 0, c->stream));
     c->ray_list_fresh = false;     // a raycast that follows renders from this pose, not from the tracked one
     return KFH_OK;

@@ -135,7 +135,20 @@ struct FinishArgs {
     int frame;
     int integration_rate;
     kfh_frame_status *status_ring;
+    unsigned *mail;           // host-visible record {pose[16], tracked, ..., [31] = mail_seq}, or null: see PoseMail
+    unsigned mail_seq;
 };
+
+// The accepted pose of a frame in host memory the device can write (pinned, mapped, coherent): a caller that waits
+// for the pose after every frame reads it from here once the stream has drained, instead of paying for a
+// device-to-host copy of 64 bytes (the copy engine's hand-overs cost more than a frame's integration).
+struct PoseMail {
+    float pose[16];
+    int tracked;
+    int pad_[14];
+    unsigned seq;             // written last: the launch number the record belongs to
+};
+static_assert(sizeof(PoseMail) == 128, "PoseMail is addressed as 32 dwords");
 
 // level1 / level2 (both or neither): also write the two robust half-samplings of the filtered image
 hipError_t launch_preprocess(float *raw, float *filtered, int ow, int oh, const void *in, bool in_is_u16,

@@ -1401,6 +1401,15 @@ __device__ inline void finish_tracking_wave(const FinishArgs &a, Mat4 pose, cons
         unsigned *st = reinterpret_cast<unsigned *>(a.status_ring + (a.frame % KFH_STATUS_RING));
         for (int d = lane; d < KFH_STATUS_DWORDS; d += 64) st[d] = status_img[d];
     }
+    if (a.mail) {
+        // the record in host memory: pose and flag first, the launch number behind a release so that a reader who
+        // sees the number also sees the record
+        if (lane < 16) a.mail[lane] = status_img[KFH_STATUS_DW(pose) + lane];
+        if (lane == 16) a.mail[16] = (unsigned)tracked;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0) __hip_atomic_store(a.mail + 31, a.mail_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 // Last launch of tracking: finalise the last iteration, then checkPoseKernel and the derived matrices.  The
@@ -1437,7 +1446,13 @@ hipError_t launch_icp_finish(const FinishArgs &a, hipStream_t s) {
 }
 
 __global__ void k_track_skip(FinishArgs a) {
-    if (threadIdx.x == 0) finish_tracking(a, false, 0, 0);
+    if (threadIdx.x != 0) return;
+    finish_tracking(a, false, 0, 0);
+    if (a.mail) {
+        for (int i = 0; i < 16; ++i) a.mail[i] = __builtin_bit_cast(unsigned, a.ctrl->pose.m[i]);
+        a.mail[16] = 0u;
+        __hip_atomic_store(a.mail + 31, a.mail_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 hipError_t launch_track_skip(const FinishArgs &a, hipStream_t s) {

@@ -201,6 +201,37 @@ def test_reset_and_set_pose(torch_cuda):
     kf.close()
 
 
+@pytest.mark.parametrize("tracking_rate", [1, 2])
+def test_pose_read_after_every_frame(torch_cuda, tracking_rate):
+    """A caller that reads the pose after every frame (the plugin does) is served from a record the finish launch
+    leaves in host memory, from its second frame on; the poses must be those of the device's status records bit for
+    bit, through a reset, a pose set by the caller and frames that skip tracking."""
+    cfg = KFusionConfig(compute_size_ratio=4, volume_resolution=(128, 128, 128), tracking_rate=tracking_rate)
+    depth, gt, ts = synth.make_sequence(10, seed=1)
+    kf = KFusion(cfg)
+    seen = []
+    for i in range(10):
+        kf.process_frame(depth[i])
+        seen.append(kf.pose.copy())
+    for i in range(10):
+        assert np.array_equal(seen[i], kf.status(i)["pose"]), i
+    assert not np.array_equal(seen[9], seen[0])
+    q = np.eye(4, dtype=np.float32)
+    q[:3, 3] = (2.0, 2.5, 1.0)
+    kf.set_pose(q)
+    assert np.array_equal(kf.pose, q)                        # not the record of the last tracked frame
+    kf.reset()
+    again = []
+    for i in range(10):
+        kf.process_frame(depth[i])
+        if i != 4:                                           # a frame without a read: the next one has no record
+            again.append(kf.pose.copy())
+        else:
+            again.append(seen[4])
+    assert all(np.array_equal(a, b) for a, b in zip(again, seen))
+    kf.close()
+
+
 def test_phase_timing(torch_cuda):
     cfg = KFusionConfig(compute_size_ratio=2, volume_resolution=(128, 128, 128))
     depth, _, _ = synth.make_sequence(6, seed=1)
