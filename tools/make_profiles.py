@@ -81,7 +81,50 @@ def dense(tag, base, volume=512):
     print(json.dumps({k: v for k, v in out.items() if k != "leg_under_kernel_trace"}, indent=1))
 
 
+def gather(tag, base):
+    """profiles/TAG_gather_efficiency.json: per kernel, what the lanes asked of the L1, what the L1 asked of the L2 and
+    what came from beyond the L2 (the latter from TAG_pmc_per_kernel.json), plus the march's sample statistics."""
+    prof = os.path.join(ROOT, "profiles")
+    pmc = {}
+    for d in (os.path.join(base, "sq"), os.path.join(base, "tcp")):
+        for k, cs in pmc_means(d).items():
+            pmc.setdefault(k, {}).update(cs)
+    hbm = {}
+    try:
+        with open(os.path.join(prof, tag + "_pmc_per_kernel.json")) as f:
+            hbm = json.load(f)
+    except OSError:
+        pass
+    out = {}
+    for k, cs in sorted(pmc.items()):
+        if not any(x in k for x in ("raycast", "integrate", "icp_iteration", "preprocess")) or "TCP_TOTAL_CACHE_ACCESSES_sum" not in cs:
+            continue
+        acc, req = cs["TCP_TOTAL_CACHE_ACCESSES_sum"]["mean"], cs["TCP_TCC_READ_REQ_sum"]["mean"]
+        rec = {"vector_load_instructions": cs.get("SQ_INSTS_VMEM_RD", {}).get("mean"),
+               "valu_instructions": cs.get("SQ_INSTS_VALU", {}).get("mean"),
+               "l1_line_accesses": acc, "l1_to_l2_read_requests": req,
+               "l1_hit_rate": 1.0 - req / acc if acc else None, "l2_to_l1_bytes": req * 64.0}
+        h = hbm.get(k, {})
+        if "FETCH_SIZE" in h:
+            rec["beyond_l2_fetch_bytes"] = 2.0 * h["FETCH_SIZE"]["mean"] * 1024.0
+            rec["beyond_l2_write_bytes"] = h["WRITE_SIZE"]["mean"] * 1024.0
+        out[k] = rec
+    try:
+        with open(os.path.join(base, "raycast_stats.txt")) as f:
+            out["raycast_march_sample_statistics"] = [line.rstrip() for line in f if line.strip()]
+    except OSError:
+        pass
+    out["note"] = ("means per launch on the benchmark stream (rocprofv3 --pmc, two passes of bench.py --steps 60); "
+                   "l2_to_l1_bytes = 64 B x L1-to-L2 read requests; beyond_l2_* from the FETCH_SIZE / WRITE_SIZE passes "
+                   "(FETCH_SIZE doubled per the gfx950 correction; it does not tell infinity-cache hits from HBM reads)")
+    with open(os.path.join(prof, tag + "_gather_efficiency.json"), "w") as f:
+        json.dump(out, f, indent=1)
+    print(json.dumps(out, indent=1))
+
+
 def main():
+    if sys.argv[1] == "--gather":
+        return gather(sys.argv[2], sys.argv[3])
     if sys.argv[1] == "--dense":
         return dense(sys.argv[2], sys.argv[3], int(sys.argv[4]) if len(sys.argv) > 4 else 512)
     tag, frames, kt, fd, wd = sys.argv[1], int(sys.argv[2]), sys.argv[3], sys.argv[4], sys.argv[5]
