@@ -2102,6 +2102,8 @@ hipError_t launch_fill_volume(short2 *vol, size_t nvox, hipStream_t s) {
 constexpr int RAY_BATCH = 4;        // steps one lane keeps in flight for its own ray
 constexpr int RAY_MAX_ROUNDS = 10;  // first pass: at most 40 samples per ray (the median ray needs about 32); 14 rounds for
                                     //   volumes beyond 1024 voxels per side, whose fine step is shorter
+constexpr int RAY_MAX_HEAVY = 6;    // first pass: at most this many rounds that fetch voxels (frames/s with 4 / 5 / 6 / 7 / 8 /
+                                    //   no limit: 5356 / 5610 / 5690 / 5682 / 5671 / 5640)
 constexpr int RAY_FEW = 8;          // first pass ends for a wavefront with at most this many live rays
 constexpr int RAY_TAIL_BLOCKS = 1024;
 
@@ -2358,7 +2360,7 @@ __global__ __launch_bounds__(256, 5) void k_raycast_march(float4 *__restrict__ v
                                                        const Mat4 *__restrict__ view_p, float near_plane,
                                                        float far_plane, float step, float largestep,
                                                        RayTask *__restrict__ tasks, unsigned *task_count,
-                                                       int max_rounds, int few, unsigned long long *dbg) {
+                                                       int max_rounds, int few, int max_heavy, unsigned long long *dbg) {
     // 16x16 pixel block, each wavefront an 8x8 tile
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // diagnostics (dbg != null): per wavefront {start, end} of the 100 MHz counter, batches, rays handed over
@@ -2388,13 +2390,13 @@ __global__ __launch_bounds__(256, 5) void k_raycast_march(float4 *__restrict__ v
         }
     }
 
-    int rounds = 0;
+    int rounds = 0, heavy_rounds = 0;
     unsigned dbg_samples = 0, dbg_skipped = 0, dbg_heavy_rounds = 0;
     unsigned long long dbg_heavy_ticks = 0, dbg_loop_t0 = 0, dbg_loop_t1 = 0;
     if (dbg) dbg_loop_t0 = __builtin_amdgcn_s_memrealtime();
     while (true) {
         const unsigned long long alive = __ballot(marching);
-        if (alive == 0 || (int)__popcll(alive) <= few || rounds == max_rounds) break;
+        if (alive == 0 || (int)__popcll(alive) <= few || rounds == max_rounds || heavy_rounds >= max_heavy) break;
         ++rounds;
         bool dbg_round_heavy = false;
         unsigned long long dbg_round_t0 = 0;
@@ -2479,6 +2481,7 @@ __global__ __launch_bounds__(256, 5) void k_raycast_march(float4 *__restrict__ v
             }
             if (active) t = tk[RAY_BATCH - 1] + stepsize;
         }
+        if (__ballot(dbg_round_heavy)) ++heavy_rounds;
         if (dbg && __ballot(dbg_round_heavy)) {
             dbg_heavy_rounds += 1;
             dbg_heavy_ticks += __builtin_amdgcn_s_memrealtime() - dbg_round_t0;
@@ -2696,11 +2699,16 @@ static hipError_t launch_raycast_t(float4 *vertex, float4 *normal, float *ray_t,
     const int res_max = res[0] > res[1] ? (res[0] > res[2] ? res[0] : res[2]) : (res[1] > res[2] ? res[1] : res[2]);
     const int max_rounds = forced_rounds > 0 ? forced_rounds : (res_max > 1024 ? 14 : RAY_MAX_ROUNDS);
     static const int few = std::getenv("KFH_RAY_FEW") ? std::atoi(std::getenv("KFH_RAY_FEW")) : RAY_FEW;
+    // a wavefront whose rays keep fetching voxels (they run along a surface) hands them over after RAY_MAX_HEAVY such
+    // rounds: the launch ends with its slowest wavefront, and the second pass spreads those rays over the device
+    // (2048^3, frames/s with 6 / 8 / 10 / no limit: 2327 / 2385 / 2376 / 2367)
+    static const int forced_heavy = std::getenv("KFH_RAY_HEAVY") ? std::atoi(std::getenv("KFH_RAY_HEAVY")) : 0;
+    const int max_heavy = forced_heavy > 0 ? forced_heavy : (res_max > 1024 ? RAY_MAX_HEAVY + 2 : RAY_MAX_HEAVY);
     static const int tail_lanes = std::getenv("KFH_RAY_TAIL_LANES") ? std::atoi(std::getenv("KFH_RAY_TAIL_LANES")) : 32;
     if (part != RAYCAST_TAIL)
         hipLaunchKernelGGL((k_raycast_march<POW2, OFFW>), grid, dim3(256), 0, s, vertex, normal, ray_t, ref_tn, w, h, v, zc0, zc1,
                            view, near_plane, far_plane, step, largestep, static_cast<RayTask *>(tasks), task_count,
-                           max_rounds, few, g_raycast_debug);
+                           max_rounds, few, max_heavy, g_raycast_debug);
     if (part == RAYCAST_MARCH) return hipGetLastError();
     const RayTask *ct = static_cast<const RayTask *>(tasks);
     if (pre != nullptr && tail_lanes == 32) {
