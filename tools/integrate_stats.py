@@ -11,7 +11,7 @@ from slambench_amd.kfusion import KFusion
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 V = int(sys.argv[2]) if len(sys.argv) > 2 else 512
-zchunk = 16 if V <= 512 else 32 if V <= 1024 else 64
+zchunk = 16 if V <= 512 else 32
 cfg = KFusionConfig(intrinsics=TUM_FR1_DEPTH_INTRINSICS, volume_resolution=(V,) * 3)
 depth, gt, ts = synth.make_sequence(n, seed=1, intrinsics=TUM_FR1_DEPTH_INTRINSICS, noise=True)
 kf = KFusion(cfg)
