@@ -613,13 +613,13 @@ int kfh_integrate(kfh_context *c) {
     if ((c->frame % c->cfg.integration_rate) == 0 || c->frame <= 3) {
         const float *src = c->cfg.integrate_filtered ? c->d_scaled[0] : c->d_float_depth;
         if (!c->box_list_fresh)      // no kfh_track since the last integration: the list still holds that one's boxes
-            KFH_HIP(hipMemsetAsync(&c->d_ctrl->integrate_box_count, 0, sizeof(unsigned), c->stream));
+            KFH_HIP(hipMemsetAsync(c->d_ctrl->integrate_box_count, 0, 2 * sizeof(unsigned), c->stream));
         c->box_list_fresh = false;
         // planes [zs0, zs1) are stored; the kernel replays the z < zs0 steps of each column arithmetically
         KFH_HIP(launch_integrate(c->d_volume, c->cfg.vol_res, c->cfg.vol_dim, c->zs0, c->zs1, src, c->w, c->h,
                                  &c->d_ctrl->inv_pose, camera_matrix(c->k[0], c->k[1], c->k[2], c->k[3]),
                                  c->cfg.mu, MAX_WEIGHT, &c->d_ctrl->integrate_gate, c->d_integrate_boxes,
-                                 &c->d_ctrl->integrate_box_count, c->d_bricks, tile_max_for_integrate(c), c->stream,
+                                 c->d_ctrl->integrate_box_count, c->d_bricks, tile_max_for_integrate(c), c->stream,
                                  &c->d_ctrl->integrate_boxes_total));
     }
     if (timed_frame(c)) {
@@ -1041,18 +1041,21 @@ int kfh_debug_integrate_stats(kfh_context *c, unsigned long long *h_out, size_t 
     unsigned long long *d = nullptr;
     KFH_HIP(hipMalloc(reinterpret_cast<void **>(&d), n_values * sizeof(unsigned long long)));
     KFH_HIP(hipMemset(d, 0, n_values * sizeof(unsigned long long)));
-    KFH_HIP(hipMemsetAsync(&c->d_ctrl->integrate_box_count, 0, sizeof(unsigned), c->stream));
+    KFH_HIP(hipMemsetAsync(c->d_ctrl->integrate_box_count, 0, 2 * sizeof(unsigned), c->stream));
     set_integrate_debug(d);
     c->box_list_fresh = false;
     const float *src = c->cfg.integrate_filtered ? c->d_scaled[0] : c->d_float_depth;
     hipError_t e = launch_integrate(c->d_volume, c->cfg.vol_res, c->cfg.vol_dim, c->zs0, c->zs1, src, c->w, c->h,
                                     &c->d_ctrl->inv_pose, camera_matrix(c->k[0], c->k[1], c->k[2], c->k[3]),
                                     c->cfg.mu, MAX_WEIGHT, nullptr, c->d_integrate_boxes,
-                                    &c->d_ctrl->integrate_box_count, c->d_bricks, tile_max_for_integrate(c), c->stream);
+                                    c->d_ctrl->integrate_box_count, c->d_bricks, tile_max_for_integrate(c), c->stream);
     set_integrate_debug(nullptr);
-    if (e == hipSuccess) e = hipMemcpyAsync(h_out + n_values - 1, &c->d_ctrl->integrate_box_count, sizeof(unsigned),
-                                            hipMemcpyDeviceToHost, c->stream);
+    unsigned counts[2] = {0, 0};
+    if (e == hipSuccess) e = hipMemcpyAsync(counts, c->d_ctrl->integrate_box_count, sizeof(counts), hipMemcpyDeviceToHost,
+                                            c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    // items of the front part take the record slots [0, counts[0]), those of the back part follow
+    h_out[n_values - 1] = (unsigned long long)counts[0] + counts[1];
     if (e == hipSuccess) e = hipMemcpy(h_out, d, (n_values - 1) * sizeof(unsigned long long), hipMemcpyDeviceToHost);
     (void)hipFree(d);
     KFH_HIP(e);
@@ -1193,7 +1196,7 @@ int kfh_k_integrate(void *d_volume, const int32_t res[3], const float dim[3], in
     Mat4 Km;
     std::memcpy(Km.m, K, sizeof(Km.m));
     hipError_t e = hipMemcpyAsync(d_inv, invTrack, sizeof(Mat4), hipMemcpyHostToDevice, s);
-    if (e == hipSuccess) e = hipMemsetAsync(d_count, 0, sizeof(unsigned), s);
+    if (e == hipSuccess) e = hipMemsetAsync(d_count, 0, 2 * sizeof(unsigned), s);
     if (e == hipSuccess)
         e = launch_integrate(static_cast<short2 *>(d_volume), res, dim, z0, z1, d_depth, w, h, d_inv, Km, mu,
                              maxweight, nullptr, scratch + 512, d_count, nullptr, nullptr, s);

@@ -38,8 +38,9 @@ struct Ctrl {
     int integrate_gate; // this frame fuses its depth map: (tracked and rate hit) or frame <= 3
     int frame;          // frame counter (device copy)
     unsigned ray_task_count;  // rays the first raycast pass handed to the second (reset by the tracking finish)
-    unsigned integrate_box_count;  // boxes the integrate plan launch kept (reset by the tracking finish)
-    int pad_[3];
+    unsigned integrate_box_count[2];  // work items the integrate plan launch made: [0] the long ones, appended from the
+                                      //   front of the list, [1] the short ones, from its back (reset by the tracking finish)
+    int pad_[2];
     // running totals since the context was created or reset (never cleared by the frame kernels): boxes the plan
     // launches kept, and plan launches whose gate was open.  A benchmark reads them before and after a run.
     unsigned long long integrate_boxes_total;
@@ -177,7 +178,7 @@ hipError_t launch_update_pose(float *pose16, double *x6, int *converged, const f
 hipError_t launch_update_pose_chain(float *pose16, const float *sums, float thr, int n, hipStream_t s);
 hipError_t launch_pose_derive(Ctrl *ctrl, const float k[4], int set_raycast_pose, hipStream_t s);
 // Two launches: a plan launch lists the 64 x 4 x zchunk boxes that can touch the camera frustum, the work launch
-// fuses the depth map into those.  `boxes` holds integrate_box_list_bytes() bytes and *box_count must be zero
+// fuses the depth map into those.  `boxes` holds integrate_box_list_bytes() bytes and box_count[0], box_count[1] must be zero
 // when the first launch starts.
 size_t integrate_box_list_bytes(const int res[3], int z1);
 hipError_t launch_integrate(short2 *vol, const int res[3], const float dim[3], int z0, int z1,

@@ -771,7 +771,7 @@ __device__ void finish_tracking(const FinishArgs &a, bool ran_tracking, int iter
     }
     c->tracked = tracked;
     c->ray_task_count = 0;      // the raycast of this frame appends its unfinished rays from here
-    c->integrate_box_count = 0; // likewise the box list of this frame's integration
+    c->integrate_box_count[0] = c->integrate_box_count[1] = 0; // likewise the work list of this frame's integration
     const int integrated = ((tracked && (a.frame % a.integration_rate) == 0) || a.frame <= 3) ? 1 : 0;
     c->integrate_gate = integrated;
     c->frame = a.frame;
@@ -1365,8 +1365,9 @@ __device__ inline void finish_tracking_wave(const FinishArgs &a, Mat4 pose, cons
         ctrl_img[KFH_CTRL_DW(integrate_gate)] = (unsigned)integrated;
         ctrl_img[KFH_CTRL_DW(frame)] = (unsigned)a.frame;
         ctrl_img[KFH_CTRL_DW(ray_task_count)] = 0u;        // this frame's raycast appends its unfinished rays from here
-        ctrl_img[KFH_CTRL_DW(integrate_box_count)] = 0u;   // likewise the box list of this frame's integration
-        for (int i = 0; i < 3; ++i) ctrl_img[KFH_CTRL_DW(pad_) + i] = 0u;
+        ctrl_img[KFH_CTRL_DW(integrate_box_count)] = 0u;   // likewise the work list of this frame's integration
+        ctrl_img[KFH_CTRL_DW(integrate_box_count) + 1] = 0u;
+        for (int i = 0; i < 2; ++i) ctrl_img[KFH_CTRL_DW(pad_) + i] = 0u;
         // the record the next frame's first iteration starts from
         const int st = KFH_CTRL_DW(icp);
         put_mat(ctrl_img, st + (int)(offsetof(IcpState, pose) / 4), pose);
@@ -1605,7 +1606,9 @@ struct IntegrateArgs {
                                 //   touch the camera frustum.  x = bx | by << 8 | first bz << 20 | inside-the-image << 28
                                 //   (every voxel of the item is in front of the camera and projects into the image),
                                 //   y = mask of its boxes
-    unsigned *box_count;
+    unsigned *box_count;        // two counters: items appended from the front of the list (the long ones: they start
+                                //   first, so that the launch does not end with one of them) and from its back
+    unsigned list_capacity;     // entries of `boxes`
     int min_group;              // boxes per work item: a power of two between min_group and 32, chosen per launch so
     int target_items;           //   that about target_items items come out (from the previous launch's box count)
     unsigned char *bricks;      // per 8^3 brick: 1 while no voxel of the brick (plus one voxel past it) went
@@ -1796,22 +1799,34 @@ __global__ __launch_bounds__(256) void k_integrate_plan(IntegrateArgs a) {
         const bool leader = r == 0 && gm != 0u;
         const unsigned long long lm = __ballot(leader);
         const int first = __ffsll((long long)lm) - 1;
-        unsigned base = 0;
+        // An item's cost grows with the planes it marches and, more slowly, with the planes it replays first.  Items in
+        // the upper half of what an item of this launch can cost go to the front of the list, the others to its back;
+        // the work launch takes the front first.
+        // (a marched plane costs about sixteen replayed ones; single-box items all cost the same: they keep their order)
+        const int cost = __popc(gm) * a.zchunk * 16 + g * G * a.zchunk;
+        const bool heavy = leader && (G == 1 || 2 * cost >= G * a.zchunk * 16 + a.gz * a.zchunk);
+        const unsigned long long hm = __ballot(heavy), tm = lm & ~hm;
+        unsigned base_h = 0, base_t = 0;
         if (lane == first) {
-            base = atomicAdd(a.box_count, (unsigned)__popcll(lm));
+            if (hm) base_h = atomicAdd(a.box_count, (unsigned)__popcll(hm));
+            if (tm) base_t = atomicAdd(a.box_count + 1, (unsigned)__popcll(tm));
             if (a.totals) atomicAdd(a.totals, (unsigned long long)__popcll(m));
         }
-        base = __builtin_amdgcn_readlane(base, first);
-        if (leader)
-            a.boxes[base + __popcll(lm & ((1ull << lane) - 1ull))] =
+        base_h = __builtin_amdgcn_readlane(base_h, first);
+        base_t = __builtin_amdgcn_readlane(base_t, first);
+        if (leader) {
+            const unsigned long long below = (1ull << lane) - 1ull;
+            const unsigned at = heavy ? base_h + __popcll(hm & below) : a.list_capacity - 1u - (base_t + __popcll(tm & below));
+            a.boxes[at] =
                 make_uint2((unsigned)bx | ((unsigned)by << 8) | ((unsigned)(g * G) << 20) | (ge == 0u ? 1u << 28 : 0u), gm);
+        }
     }
 }
 
 // Second launch: a workgroup takes boxes from the list; one thread per (x, y) column of the box.
 __global__ __launch_bounds__(256, KFH_INTEGRATE_MIN_WAVES) void k_integrate(IntegrateArgs a) {
     if (!KFH_STAMPS_COMPILED) a.dbg = nullptr;      // per-wavefront statistics only in diagnostic builds
-    const unsigned nbox = *a.box_count;
+    const unsigned nfront = a.box_count[0], nbox = nfront + a.box_count[1];
     if (a.totals && blockIdx.x == 0 && threadIdx.x == 0) {
         // the plan launch has ended: what it added to the running total is this integration's box count, which
         // the next plan launch sizes its work items by
@@ -1836,7 +1851,7 @@ __global__ __launch_bounds__(256, KFH_INTEGRATE_MIN_WAVES) void k_integrate(Inte
         unsigned long long dbg_t0 = 0;
         unsigned dbg_cand = 0, dbg_written = 0;
         if (a.dbg) dbg_t0 = __builtin_amdgcn_s_memrealtime();
-        const uint2 item = a.boxes[bi];
+        const uint2 item = a.boxes[bi < nfront ? bi : a.list_capacity - 1u - (bi - nfront)];
         const int bx = item.x & 0xFF, by = (item.x >> 8) & 0xFFF, first_bz = (item.x >> 20) & 0xFF;
         unsigned group_mask = item.y;
         const bool item_inside = (item.x >> 28) & 1u;
@@ -2064,6 +2079,7 @@ hipError_t launch_integrate(short2 *vol, const int res[3], const float dim[3], i
     a.zchunk = integrate_zchunk(z1);
     a.gx = (res[0] + 63) / 64; a.gy = (res[1] + 3) / 4; a.gz = (z1 + a.zchunk - 1) / a.zchunk;
     a.boxes = static_cast<uint2 *>(boxes); a.box_count = box_count;
+    a.list_capacity = (unsigned)(integrate_box_list_bytes(res, z1) / sizeof(uint2));
     a.min_group = integrate_min_group(z1); a.target_items = integrate_target_items();
     a.bricks = bricks; a.bgx = (res[0] + 7) / 8; a.bgy = (res[1] + 7) / 8;
     a.tile_max = tile_max; a.tiles_x = (w + PRE_TX - 1) / PRE_TX; a.tiles_y = (h + PRE_TY - 1) / PRE_TY;
@@ -2946,7 +2962,7 @@ hipError_t launch_render_shade(uchar4 *out, const float4 *vertex, const float4 *
 
 __global__ void k_store_mat4(Mat4 *out, Mat4 m, unsigned *zeroed) {
     if (threadIdx.x < 16) out->m[threadIdx.x] = m.m[threadIdx.x];
-    if (threadIdx.x == 16 && zeroed) *zeroed = 0u;
+    if ((threadIdx.x == 16 || threadIdx.x == 17) && zeroed) zeroed[threadIdx.x - 16] = 0u;     // the two list counters
 }
 
 hipError_t launch_store_mat4(Mat4 *d_out, const Mat4 &m, unsigned *d_zeroed, hipStream_t s) {
