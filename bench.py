@@ -67,6 +67,10 @@ def parse_args():
     ap.add_argument("--icp", choices=["replicated", "allreduce"], default="replicated",
                     help="--mode zslab: every rank tracks the whole image (no collective), or every rank tracks its "
                          "rows and the 32 ICP sums are all-reduced per iteration")
+    ap.add_argument("--exchange", choices=["gather", "tiles"], default="gather",
+                    help="--mode zslab: one all-gather of every rank's slab candidates (16 B per pixel and rank), or "
+                         "an all-to-all that gives every rank the candidates of its 1/N of the image followed by an "
+                         "all-gather of the selected shares (2/N of the bytes, two collectives)")
     ap.add_argument("--force-exchange", action="store_true",
                     help="--mode zslab on ONE rank: still take the exchange path (slab march, all-gather, composite, "
                          "all-reduce) through a single-rank RCCL group, to time the collectives' fixed cost")
@@ -247,7 +251,8 @@ def main():
 
     if zslab:
         from slambench_amd.sharded import SlabKFusion
-        sharded = SlabKFusion(cfg, rank, world, dist, torch, icp=a.icp, force_exchange=solo_exchange)
+        sharded = SlabKFusion(cfg, rank, world, dist, torch, icp=a.icp, force_exchange=solo_exchange,
+                              exchange=a.exchange)
         kf = sharded.kf
         step = sharded.process_frame
     else:
@@ -396,8 +401,9 @@ def main():
                 "compute_size": "%dx%d" % cfg.compute_size, "volume": V,
                 "input": "every depth frame is resident in HBM before the timed region starts (value has no upload in "
                          "it); pcie_inclusive_frames_per_s is the same stream with one host-to-device upload per frame",
-                "parallelism": ("one sequence, volume in %d z-slabs, raycast segments all-gathered, ICP %s (%s)"
-                                % (world, a.icp, backend)
+                "parallelism": ("one sequence, volume in %d z-slabs, raycast segments %s, ICP %s (%s)"
+                                % (world, "all-gathered" if a.exchange == "gather" else
+                                   "exchanged by image share (all-to-all + all-gather)", a.icp, backend)
                                 if zslab else "%d sequence(s) per rank (replicas, no collective; %s)" % (1 + len(extra), backend)
                                 if world > 1 else "%d sequence(s) on one GPU" % (1 + len(extra)) if extra else "single GPU"),
             },

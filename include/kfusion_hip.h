@@ -188,6 +188,14 @@ int kfh_raycast_slab(kfh_context *ctx);
 /* Keep, per pixel, the candidate with the smallest positive t among n_parts gathered slab results.
  * d_tn_parts: float4[n_parts][h][w] in the layout of KFH_BUF_MODEL_TN; the winners become the context's model map. */
 int kfh_composite_slabs(kfh_context *ctx, const void *d_tn_parts, int n_parts);
+/* The same selection on a range of pixels only: d_tn_parts is float4[n_parts][pixel_count], the candidates of
+ * pixels [first_pixel, first_pixel + pixel_count) (row-major pixel numbers); the winners go to d_out
+ * (float4[pixel_count]), or into the context's own packed map at first_pixel when d_out is NULL.  For exchanges
+ * that split the image among the devices instead of giving every device every slab: an all-to-all hands each
+ * device the candidates of its share (1/N of the bytes of the all-gather above), this call selects, and an
+ * all-gather of the selected shares into KFH_BUF_MODEL_TN completes the map on every device. */
+int kfh_composite_tile(kfh_context *ctx, const void *d_tn_parts, int n_parts, int first_pixel, int pixel_count,
+                       void *d_out);
 /* Kfusion::tracking with the pixels of every pyramid level split by rows over share_count devices that all hold the
  * same model map and depth frame (what z-slab ranks do).  This context evaluates share `share`.  After every
  * iteration launch the library folds this device's partial sums into one row of 32 floats (reduceKernel layout) and

@@ -723,6 +723,22 @@ int kfh_composite_slabs(kfh_context *c, const void *d_tn_parts, int n_parts) {
     return KFH_OK;
 }
 
+int kfh_composite_tile(kfh_context *c, const void *d_tn_parts, int n_parts, int first_pixel, int pixel_count,
+                       void *d_out) {
+    KFH_REQUIRE(c != nullptr && d_tn_parts != nullptr, "NULL argument");
+    DeviceScope on_device(c->device);
+    if (int rc = flush_tail(c)) return rc;
+    KFH_REQUIRE(n_parts >= 1 && n_parts <= 64, "n_parts=%d out of range", n_parts);
+    KFH_REQUIRE(first_pixel >= 0 && pixel_count >= 1 && first_pixel <= c->w * c->h - pixel_count,
+                "pixels [%d, %d + %d) do not lie inside the %d x %d image", first_pixel, first_pixel, pixel_count, c->w, c->h);
+    if (c->frame > 2) {
+        c->model_maps_stale = true;      // the caller completes the packed map behind this call
+        float4 *out = d_out ? static_cast<float4 *>(d_out) : c->d_ref_tn + first_pixel;
+        KFH_HIP(launch_composite(out, static_cast<const float4 *>(d_tn_parts), n_parts, pixel_count, c->stream));
+    }
+    return KFH_OK;
+}
+
 int kfh_enable_track_render(kfh_context *c, int enabled) {
     KFH_REQUIRE(c != nullptr, "context is NULL");
     DeviceScope on_device(c->device);

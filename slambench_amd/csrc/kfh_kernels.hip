@@ -2719,7 +2719,9 @@ static hipError_t launch_raycast_t(float4 *vertex, float4 *normal, float *ray_t,
     // rounds: the launch ends with its slowest wavefront, and the second pass spreads those rays over the device
     // (2048^3, frames/s with 6 / 8 / 10 / no limit: 2327 / 2385 / 2376 / 2367)
     static const int forced_heavy = std::getenv("KFH_RAY_HEAVY") ? std::atoi(std::getenv("KFH_RAY_HEAVY")) : 0;
-    const int max_heavy = forced_heavy > 0 ? forced_heavy : (res_max > 1024 ? RAY_MAX_HEAVY + 2 : RAY_MAX_HEAVY);
+    // (without brick marks every round fetches voxels: the limit then would end the first pass for all rays)
+    const int max_heavy = forced_heavy > 0 ? forced_heavy
+                          : bricks == nullptr ? 1 << 20 : (res_max > 1024 ? RAY_MAX_HEAVY + 2 : RAY_MAX_HEAVY);
     static const int tail_lanes = std::getenv("KFH_RAY_TAIL_LANES") ? std::atoi(std::getenv("KFH_RAY_TAIL_LANES")) : 32;
     if (part != RAYCAST_TAIL)
         hipLaunchKernelGGL((k_raycast_march<POW2, OFFW>), grid, dim3(256), 0, s, vertex, normal, ray_t, ref_tn, w, h, v, zc0, zc1,

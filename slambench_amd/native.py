@@ -26,7 +26,7 @@ EXPORTED_SYMBOLS = (
     "kfh_sync",
     "kfh_get_pose", "kfh_set_pose", "kfh_get_status", "kfh_frame_index", "kfh_integrate_totals", "kfh_compute_size",
     "kfh_download", "kfh_device_ptr", "kfh_stream", "kfh_set_timing", "kfh_phase_ms", "kfh_phase_ms_frame",
-    "kfh_raycast_slab", "kfh_composite_slabs", "kfh_track_rows",
+    "kfh_raycast_slab", "kfh_composite_slabs", "kfh_composite_tile", "kfh_track_rows",
     "kfh_render", "kfh_render_device", "kfh_enable_track_render",
     "kfh_k_render_depth", "kfh_k_render_track", "kfh_k_render_volume",
     "kfh_k_preprocess", "kfh_k_bilateral", "kfh_k_half_sample", "kfh_k_vertex_normal",
@@ -84,6 +84,7 @@ def lib():
         "kfh_stream": [vp, C.POINTER(vp)],
         "kfh_set_timing": [vp, i32], "kfh_phase_ms": [vp, vp], "kfh_phase_ms_frame": [vp, i32, vp],
         "kfh_raycast_slab": [vp], "kfh_composite_slabs": [vp, vp, i32],
+        "kfh_composite_tile": [vp, vp, i32, i32, i32, vp],
         "kfh_track_rows": [vp, i32, i32, ALLREDUCE_FN, vp],
         "kfh_k_preprocess": [vp, vp, i32, i32, vp, i32, i32, f32, vp],
         "kfh_k_bilateral": [vp, vp, i32, i32, vp],

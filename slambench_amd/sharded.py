@@ -7,7 +7,10 @@ on all ranks without an all-reduce (icp="allreduce" splits the pixels by rows in
 after every iteration: kfh_track_rows).  The only other exchange step of a frame is the raycast: each rank marches
 the part of every ray that lies inside its slab, the per-slab results (hit distance and normal: 16 bytes per pixel;
 the vertex is a function of the pixel and the distance) are all-gathered in one collective, and every rank keeps the
-nearest hit per pixel (kfh_composite_slabs).
+nearest hit per pixel (kfh_composite_slabs).  exchange="tiles" splits the image among the ranks instead: an all-to-all
+hands every rank the N candidates of its 1/N of the pixels, the rank selects (kfh_composite_tile), and an all-gather of
+the selected shares completes the map everywhere: two collectives that move 2/N of the bytes of the single all-gather,
+which is what counts on point-to-point links once N is 4 or 8.
 
 The reference has no multi-device path at all (no NCCL/MPI anywhere in its tree); this module is the new
 component the volume-size axis of the reference's design space (volume-resolution) needs on an 8-GPU node.
@@ -60,11 +63,13 @@ class SlabKFusion:
     the 32 ICP sums are all-reduced after every iteration (kfh_track_rows); 19 small collectives per frame."""
 
     def __init__(self, cfg: KFusionConfig, rank=0, world_size=1, dist=None, torch=None, icp="replicated",
-                 force_exchange=False):
+                 force_exchange=False, exchange="gather"):
         """force_exchange: take the exchange path (slab march, all-gather, composite, and the all-reduce when
         icp="allreduce") even in a world of one rank: a one-GPU box can then run the device-side collectives."""
         if icp not in ("replicated", "allreduce"):
             raise ValueError("icp must be 'replicated' or 'allreduce'")
+        if exchange not in ("gather", "tiles"):
+            raise ValueError("exchange must be 'gather' or 'tiles'")
         self.rank, self.world = rank, world_size
         self.dist, self.torch = dist, torch
         self.exchange = world_size > 1 or (force_exchange and dist is not None)
@@ -74,6 +79,11 @@ class SlabKFusion:
         self.kf = KFusion(self.cfg)
         w, h = self.cfg.compute_size
         self.npix = w * h
+        if exchange == "tiles" and self.npix % world_size != 0:
+            raise ValueError("exchange='tiles' needs a pixel count (%d) divisible by the number of ranks (%d)"
+                             % (self.npix, world_size))
+        self.exchange_mode = exchange
+        self._recv = self._tile = None
         self._gathered = None
         self._mine = None
         self._sums = {}
@@ -132,6 +142,41 @@ class SlabKFusion:
             torch.cuda.synchronize()
         return self._gathered.data_ptr()
 
+    def _exchange_tiles(self):
+        """The raycast exchange with the image split among the ranks: all-to-all of the candidates, selection of this
+        rank's share, all-gather of the selected shares into the packed model map."""
+        torch, dist, kf = self.torch, self.dist, self.kf
+        n, share = self.world, self.npix // self.world
+        if self._mine is None:
+            ptr, _ = kf.device_ptr(native.BUF_MODEL_TN)
+            self._mine = _wrap_device_buffer(torch, ptr, self.cfg.compute_size[::-1] + (4,))
+        if self._recv is None:
+            self._recv = torch.empty((n, share, 4), dtype=torch.float32, device="cuda")
+            self._tile = torch.empty((share, 4), dtype=torch.float32, device="cuda")
+        mine = self._mine.view(-1)
+        if self._device_collectives:
+            with torch.cuda.stream(self._stream):
+                dist.all_to_all_single(self._recv.view(-1), mine)
+        else:                             # gloo: through the host
+            kf.sync()
+            host = mine.cpu()
+            got = torch.empty_like(host)
+            dist.all_to_all_single(got, host)
+            self._recv.view(-1).copy_(got)
+            torch.cuda.synchronize()
+        native.check(kf._L.kfh_composite_tile(kf._ctx, C.c_void_p(self._recv.data_ptr()), n, self.rank * share, share,
+                                              C.c_void_p(self._tile.data_ptr())))
+        if self._device_collectives:
+            with torch.cuda.stream(self._stream):
+                dist.all_gather_into_tensor(mine, self._tile.view(-1))
+        else:
+            kf.sync()
+            host = self._tile.view(-1).cpu()
+            out = [torch.empty_like(host) for _ in range(n)]
+            dist.all_gather(out, host)
+            mine.copy_(torch.cat(out))
+            torch.cuda.synchronize()
+
     # -- one frame ----------------------------------------------------------------------------------------
     def process_frame(self, depth):
         kf = self.kf
@@ -151,7 +196,10 @@ class SlabKFusion:
         else:
             native.check(kf._L.kfh_raycast_slab(kf._ctx))
             if kf.frame > 2:
-                native.check(kf._L.kfh_composite_slabs(kf._ctx, C.c_void_p(self._gather()), self.world))
+                if self.exchange_mode == "tiles":
+                    self._exchange_tiles()
+                else:
+                    native.check(kf._L.kfh_composite_slabs(kf._ctx, C.c_void_p(self._gather()), self.world))
         kf.end_frame()
 
 

@@ -2,7 +2,7 @@
 
 Runs SlabKFusion.process_frame (the code path `bench.py --mode zslab` runs) over a synthetic sequence and writes
 this rank's trajectory, tracked flags and final model maps to OUT_DIR/rank<r>.npz.
-usage (under torch.distributed.run): sharded_worker.py OUT_DIR FRAMES VOLUME ICP_MODE [BACKEND]
+usage (under torch.distributed.run): sharded_worker.py OUT_DIR FRAMES VOLUME ICP_MODE [BACKEND [EXCHANGE]]
 BACKEND nccl is only possible with one rank per GPU; with a single rank the exchange path is forced, so that the
 device-side collectives (RCCL on the context's own stream) run on a one-GPU box.
 """
@@ -22,6 +22,7 @@ from slambench_amd.sharded import SlabKFusion  # noqa: E402
 def main():
     out_dir, n, V, icp = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
     backend = sys.argv[5] if len(sys.argv) > 5 else "gloo"
+    exchange = sys.argv[6] if len(sys.argv) > 6 else "gather"
     torch.cuda.set_device(0)
     if backend == "nccl":
         dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
@@ -30,7 +31,7 @@ def main():
     rank, world = dist.get_rank(), dist.get_world_size()
     cfg = KFusionConfig(compute_size_ratio=2, volume_resolution=(V, V, V))
     depth, _, _ = synth.make_sequence(n, seed=1)
-    sk = SlabKFusion(cfg, rank, world, dist, torch, icp=icp, force_exchange=True)
+    sk = SlabKFusion(cfg, rank, world, dist, torch, icp=icp, force_exchange=True, exchange=exchange)
     for i in range(n):
         sk.process_frame(depth[i])
     kf = sk.kf

@@ -19,12 +19,14 @@ pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-def run_ranks(tmp_path, world, frames, volume, icp, backend="gloo"):
-    port = 29700 + (os.getpid() % 200) + (7 if icp == "allreduce" else 0) + (13 if backend == "nccl" else 0)
+def run_ranks(tmp_path, world, frames, volume, icp, backend="gloo", exchange="gather"):
+    port = (29700 + (os.getpid() % 200) + (7 if icp == "allreduce" else 0) + (13 if backend == "nccl" else 0)
+            + (29 if exchange == "tiles" else 0))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(HERE, "sharded_worker.py"),
-           str(tmp_path), str(frames), str(volume), icp, backend]
+           str(tmp_path), str(frames), str(volume), icp, backend, exchange]
     env = dict(os.environ, OMP_NUM_THREADS="4", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    os.makedirs(str(tmp_path), exist_ok=True)
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert "SHARDED_OK" in r.stdout
@@ -69,6 +71,21 @@ def test_two_rank_processes_match_the_in_process_slabs(torch_cuda, tmp_path):
         assert np.array_equal(r["tracked"], tracked)
         assert np.array_equal(r["vertex"], vertex)
         assert np.array_equal(r["normal"], normal)
+
+
+@pytest.mark.parametrize("world,backend", [(2, "gloo"), (3, "gloo"), (1, "nccl")])
+def test_tile_exchange_gives_the_maps_of_the_gather_exchange(torch_cuda, tmp_path, world, backend):
+    """exchange="tiles" (all-to-all of the candidates, kfh_composite_tile on this rank's share of the pixels, all-gather
+    of the selected shares) must leave every rank with the bits the single all-gather + kfh_composite_slabs leaves:
+    two and three ranks over gloo, and one rank through the device-side RCCL collectives."""
+    frames, V = 8, 126 if world == 3 else 128
+    tiles = run_ranks(tmp_path / "tiles", world, frames, V, "replicated", backend=backend, exchange="tiles")
+    gather = run_ranks(tmp_path / "gather", world, frames, V, "replicated", backend=backend, exchange="gather")
+    for a, b in zip(tiles, gather):
+        assert np.array_equal(a["trajectory"], b["trajectory"])
+        assert np.array_equal(a["vertex"], b["vertex"]) and np.array_equal(a["normal"], b["normal"])
+        assert a["tracked"][4:].all()
+    assert (tiles[0]["normal"][..., 0] != -2).mean() > 0.5
 
 
 def test_row_sharded_icp_with_allreduced_sums_matches_the_replicated_mode(torch_cuda, tmp_path):
