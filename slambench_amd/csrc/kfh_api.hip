@@ -97,7 +97,7 @@ struct kfh_context {
     float4 *d_in_vertex[3] = {nullptr, nullptr, nullptr};
     float4 *d_in_normal[3] = {nullptr, nullptr, nullptr};
     float4 *d_vertex = nullptr, *d_normal = nullptr;
-    unsigned char *d_bricks = nullptr;     // brick marks for the raycast (null when the volume is sharded)
+    unsigned char *d_bricks = nullptr;     // brick marks for the raycast (the whole volume's grid, also for a slab)
     void *d_integrate_boxes = nullptr;     // work items the integrate plan launch made for the work launch
     void *d_ray_tasks = nullptr;           // rays handed from the first raycast pass to the second
     float4 *d_ref_tn = nullptr;            // packed model map {hit distance, normal}: what tracking gathers
@@ -233,7 +233,17 @@ int init_state(kfh_context *c) {
     c->next_set = 0;
     select_set(c, 0);
     KFH_HIP(launch_fill_volume(c->d_volume, c->volume_voxels, c->stream));
-    if (c->d_bricks) KFH_HIP(hipMemsetAsync(c->d_bricks, 1, brick_mark_bytes(c->cfg.vol_res), c->stream));
+    if (c->d_bricks) {
+        // A mark vouches for the voxels of its brick and for the plane above it (the upper taps of a sample based in
+        // the brick).  A slab context only sees its own planes and two more per side: bricks that reach outside
+        // them never get a mark (the raycast then fetches their voxels); the volume's own faces need no neighbour.
+        const int Z = c->cfg.vol_res[2], bgz = (Z + 7) / 8;
+        const size_t layer = (size_t)((c->cfg.vol_res[0] + 7) / 8) * ((c->cfg.vol_res[1] + 7) / 8);
+        const int b_lo = c->zs0 == 0 ? 0 : (c->zs0 + 7) / 8;
+        const int b_hi = c->zs1 == Z ? bgz : (c->zs1 >= 9 ? (c->zs1 - 9) / 8 + 1 : 0);
+        KFH_HIP(hipMemsetAsync(c->d_bricks, 0, brick_mark_bytes(c->cfg.vol_res), c->stream));
+        if (b_hi > b_lo) KFH_HIP(hipMemsetAsync(c->d_bricks + (size_t)b_lo * layer, 1, (size_t)(b_hi - b_lo) * layer, c->stream));
+    }
     KFH_HIP(hipMemsetAsync(c->d_vertex, 0, npix * sizeof(float4), c->stream));
     KFH_HIP(hipMemsetAsync(c->d_normal, 0, npix * sizeof(float4), c->stream));
     KFH_HIP(hipMemsetAsync(c->d_ray_t, 0, npix * sizeof(float), c->stream));
@@ -358,7 +368,7 @@ int kfh_create(const kfh_config *cfg, kfh_context **out) {
     if (e == hipSuccess) e = hipMalloc(&c->d_ray_tasks, raycast_task_bytes(c->w, c->h));
     if (e == hipSuccess)
         e = hipMalloc(&c->d_integrate_boxes, integrate_box_list_bytes(cfg->vol_res, c->zs1));
-    if (e == hipSuccess && !c->sharded && std::getenv("KFH_NO_BRICK_MARKS") == nullptr)
+    if (e == hipSuccess && std::getenv("KFH_NO_BRICK_MARKS") == nullptr)
         e = hipMalloc(reinterpret_cast<void **>(&c->d_bricks), brick_mark_bytes(cfg->vol_res));
     if (e == hipSuccess) e = dev_alloc(&c->d_volume, c->volume_voxels);
     {
@@ -706,7 +716,7 @@ int kfh_raycast_slab(kfh_context *c) {
         KFH_HIP(launch_raycast(nullptr, nullptr, nullptr, c->d_ref_tn, c->w, c->h, c->d_volume,
                                c->cfg.vol_res, c->cfg.vol_dim, c->cfg.slab_z0, c->cfg.slab_z1, &c->d_ctrl->view, NEAR_PLANE,
                                FAR_PLANE, raycast_step(c->cfg), 0.75f * c->cfg.mu, c->d_ray_tasks,
-                               &c->d_ctrl->ray_task_count, nullptr, c->stream));
+                               &c->d_ctrl->ray_task_count, c->d_bricks, c->stream));
     }
     return KFH_OK;
 }
@@ -948,7 +958,7 @@ int kfh_device_ptr(kfh_context *c, int buffer, int level, void **d_ptr, size_t *
         case KFH_BUF_MODEL_TN: *d_ptr = c->d_ref_tn; *bytes = npix * sizeof(float4); break;
         case KFH_BUF_VOLUME: *d_ptr = c->d_volume; *bytes = c->volume_voxels * sizeof(short2); break;
         case KFH_BUF_BRICK_MARKS:
-            if (!c->d_bricks) return fail(KFH_ERR_STATE, "this context keeps no brick marks (sharded volume)");
+            if (!c->d_bricks) return fail(KFH_ERR_STATE, "this context keeps no brick marks (KFH_NO_BRICK_MARKS)");
             *d_ptr = c->d_bricks;
             *bytes = brick_mark_bytes(c->cfg.vol_res);
             break;

@@ -189,7 +189,8 @@ hipError_t launch_integrate(short2 *vol, const int res[3], const float dim[3], i
 // voxels of one box of the integrate work list for a volume whose last stored plane is z1 - 1
 int integrate_box_voxels(int z1);
 // One byte per 8^3-voxel brick ("nothing a coarse raycast step could notice in here"): integrate clears marks,
-// raycast skips marked bricks.  Optional (null) in both launches; whole volumes only.
+// raycast skips marked bricks.  Optional (null) in both launches; indexed by the whole volume's brick grid (a slab's
+// owner only marks bricks whose planes, and the plane above them, it stores).
 inline size_t brick_mark_bytes(const int res[3]) {
     return (size_t)((res[0] + 7) / 8) * ((res[1] + 7) / 8) * ((res[2] + 7) / 8);
 }

@@ -2772,7 +2772,8 @@ hipError_t launch_raycast_part(float4 *vertex, float4 *normal, float *ray_t, flo
                                const Mat4 *view, float near_plane, float far_plane, float step, float largestep,
                                void *tasks, unsigned *task_count, const unsigned char *bricks, int part,
                                const PreprocessLaunch *pre, hipStream_t s) {
-    if (bricks && !(z0 == 0 && z1 == res[2])) return hipErrorInvalidValue;   // marks describe whole volumes only
+    // (brick marks, when given, are indexed by the whole volume's brick grid; for a slab only bricks whose planes and
+    // the plane above them are stored may carry a mark)
     if (res[0] < 2 || res[1] < 2 || res[2] < 2) return hipErrorInvalidValue;   // a fetch takes two x-adjacent voxels
     if (pre != nullptr && (part != RAYCAST_TAIL || !pre->filtered || !pre->level1 || !pre->level2 || pre->ow % 4 != 0 ||
                            pre->oh % 4 != 0))

@@ -78,3 +78,59 @@ def test_two_slabs_reproduce_the_full_volume(torch_cuda):
     assert all(full.status(f)["tracked"] == slabs[0].status(f)["tracked"] for f in range(n))
     for kf in slabs + [full]:
         kf.close()
+
+
+def _run_slabs(torch, V, n, world):
+    base = dict(compute_size_ratio=2, volume_resolution=(V, V, V))
+    slabs = [KFusion(KFusionConfig(**base, slab=slab_bounds(V, world, r))) for r in range(world)]
+    depth, _, _ = synth.make_sequence(n, seed=1)
+    L = native.lib()
+    maps = []
+    for i in range(n):
+        for kf in slabs:
+            kf.set_depth(depth[i])
+            kf.preprocessing()
+            kf.tracking()
+            kf.integration()
+            native.check(L.kfh_raycast_slab(kf._ctx))
+        if i > 2:
+            parts = np.stack([kf.download(native.BUF_MODEL_TN) for kf in slabs])
+            maps.append(parts)
+            tn = torch.from_numpy(parts).cuda()
+            for kf in slabs:
+                native.check(L.kfh_composite_slabs(kf._ctx, C.c_void_p(tn.data_ptr()), world))
+        for kf in slabs:
+            kf.end_frame()
+    return slabs, maps
+
+
+def test_slab_raycast_with_brick_marks_equals_the_one_without(torch_cuda, monkeypatch):
+    """A slab context keeps brick marks for the bricks it can vouch for (all their planes and the plane above are
+    stored) and none for those that reach outside its planes; the slab march skips marked bricks.  Its per-slab ray
+    segments must be the bits of a march that fetches every sample's voxels."""
+    V, n, world = 128, 10, 3          # slabs of 43 / 43 / 42 planes: boundaries that are no multiples of the brick size
+    slabs, maps = _run_slabs(torch_cuda, V, n, world)
+    marks = [kf.download(native.BUF_BRICK_MARKS) for kf in slabs]
+    traj = [kf.trajectory() for kf in slabs]
+    for kf in slabs:
+        kf.close()
+    cleared_somewhere = False
+    for r, m in enumerate(marks):
+        z0, z1 = slab_bounds(V, world, r)
+        zs0, zs1 = max(z0 - 2, 0), min(z1 + 2, V)
+        bz = np.arange(V // 8)
+        inside = ((8 * bz >= zs0) | (zs0 == 0)) & ((8 * bz + 8 <= zs1 - 1) | (zs1 == V))
+        assert not m[~inside].any(), "bricks that reach outside the stored planes must never be marked"
+        assert m[inside].mean() > 0.3, "most bricks of a room are free space"
+        cleared_somewhere = cleared_somewhere or not m[inside].all()
+    assert cleared_somewhere, "the surface must have cleared marks in the slab that holds it"
+    monkeypatch.setenv("KFH_NO_BRICK_MARKS", "1")
+    plain, maps_plain = _run_slabs(torch_cuda, V, n, world)
+    traj_plain = [kf.trajectory() for kf in plain]
+    for kf in plain:
+        kf.close()
+    assert len(maps) == len(maps_plain) == n - 3
+    for a, b in zip(maps, maps_plain):
+        assert np.array_equal(a, b)
+    assert all(np.array_equal(a, b) for a, b in zip(traj, traj_plain))
+    assert (maps[-1][..., 0] > 0).any(axis=0).mean() > 0.5          # the composite hits most pixels
