@@ -1589,6 +1589,16 @@ constexpr int RAY_COARSE_SAFE = 26300;
 // This is the instruction sequence of the compiler's own IEEE division (reciprocal estimate, one Newton
 // step, two quotient corrections) without the exponent pre-scaling, which only matters for operands near
 // the ends of the float range; the integrate kernel divides metres and pixels by a depth >= 1e-4.
+// Footprint of a box in x and y (256 columns, one per lane of a workgroup).  With 128 x 2 a wavefront's 8-byte accesses
+// in the two-column march cover 512 contiguous bytes of one row instead of two 256-byte pieces in two rows; the bare
+// access pattern is 10 % faster that way, the march itself is not (dense 512^3: 219 against 220 us), and the longer
+// boxes are culled worse (the benchmark frame takes 4.76 M voxels instead of 3.03 M, 1.2 % fewer frames/s): 64 x 4.
+#ifndef KFH_BOX_X
+#define KFH_BOX_X 64
+#endif
+constexpr int BOX_X = KFH_BOX_X, BOX_Y = 256 / BOX_X;
+static_assert(BOX_X == 64 || BOX_X == 128, "a box is 64 x 4 or 128 x 2 columns");
+
 struct IntegrateArgs {
     short2 *vol;
     int sx, sy, sz;
@@ -1601,7 +1611,7 @@ struct IntegrateArgs {
     float mu, maxweight;
     const int *gate;            // device flag: 0 = this frame does not integrate
     int zchunk;
-    int gx, gy, gz;             // boxes of 64 x 4 x zchunk voxels
+    int gx, gy, gz;             // boxes of BOX_X x BOX_Y x zchunk voxels
     uint2 *boxes;               // work items: up to 32 boxes of one (bx, by) column that follow each other in z and may
                                 //   touch the camera frustum.  x = bx | by << 8 | first bz << 20 | inside-the-image << 28
                                 //   (every voxel of the item is in front of the camera and projects into the image),
@@ -1618,9 +1628,11 @@ struct IntegrateArgs {
     unsigned long long *totals; // running totals {boxes kept, launches with an open gate, boxes kept up to the previous
                                 //   launch, boxes kept by the previous launch}; may be null
     unsigned long long *dbg;
+    int vec2;                   // items inside the image are marched two columns per lane (even sx, volume 8-byte aligned,
+                                //   0 <= maxweight <= 32767)
 };
 
-// Conservative frustum culling of the box of 64 x 4 x (zc1 - zc0) voxels at (bx * 64, by * 4, zc0), grown by
+// Conservative frustum culling of the box of BOX_X x BOX_Y x (zc1 - zc0) voxels at (bx * BOX_X, by * BOX_Y, zc0), grown by
 // two voxels per side.  A voxel is only ever touched if it passes the half-space tests of the march; if all
 // eight corners of the grown box fail the same half-space, no voxel of the box can pass it (the two voxels
 // of slack are far more than the drift of the incrementally accumulated positions).
@@ -1632,10 +1644,10 @@ __device__ inline int box_class(const IntegrateArgs &a, const Mat4 &invTrack, in
                                 bool depth_test) {
     const float wmax = (float)(a.w - 1), hmax = (float)(a.h - 1);
     const float vx = a.dimx / (float)a.sx, vy = a.dimy / (float)a.sy, vz = a.dimz / (float)a.sz;
-    const float bx0 = ((float)(bx * 64 - 2) + 0.5f) * vx;
-    const float bx1 = ((float)(min(bx * 64 + 63, a.sx - 1) + 2) + 0.5f) * vx;
-    const float by0 = ((float)(by * 4 - 2) + 0.5f) * vy;
-    const float by1 = ((float)(min(by * 4 + 3, a.sy - 1) + 2) + 0.5f) * vy;
+    const float bx0 = ((float)(bx * BOX_X - 2) + 0.5f) * vx;
+    const float bx1 = ((float)(min(bx * BOX_X + BOX_X - 1, a.sx - 1) + 2) + 0.5f) * vx;
+    const float by0 = ((float)(by * BOX_Y - 2) + 0.5f) * vy;
+    const float by1 = ((float)(min(by * BOX_Y + BOX_Y - 1, a.sy - 1) + 2) + 0.5f) * vy;
     const float bz0 = ((float)(zc0 - 2) + 0.5f) * vz;
     const float bz1 = ((float)(zc1 + 1) + 0.5f) * vz;
     const f3 c0 = xform(invTrack, mk3(bx0, by0, bz0));
@@ -1669,7 +1681,13 @@ __device__ inline int box_class(const IntegrateArgs &a, const Mat4 &invTrack, in
     // into the bounding rectangle of the corners' projections (the projection of a convex set in front of the
     // camera is the convex hull of the projected corners).  The march adds 0.5 and accepts [0, w - 1] x [0, h - 1];
     // two pixels are kept in hand (the accumulated positions differ from exact ones by far less than a pixel).
-    const bool interior = all_front && pxmin >= 2.f && pxmax <= wmax - 3.f && pymin >= 2.f && pymax <= hmax - 3.f;
+    // The accumulated positions drift from the exact ones by a rounding residual that repeats from plane to plane, so
+    // the margin grows with the number of planes (2 pixels at 512 planes were ample; + 1 pixel per 512 planes).  Such
+    // an item also lies more than mu in front of the camera: a pixel without depth (0) then reads as "behind the
+    // surface" (0 - z <= -mu) with no test of its own.
+    const float margin = 2.f + (float)a.z1 * (1.f / 512.f);
+    const bool interior = all_front && zmin > a.mu + 0.01f && pxmin >= margin && pxmax <= wmax - 1.f - margin &&
+                          pymin >= margin && pymax <= hmax - 1.f - margin;
     // Behind the surface: a voxel is left untouched when the depth seen through its pixel is at least mu in
     // front of it.  With every corner of the grown box in front of the camera the box projects inside the
     // bounding rectangle of its corners; if even the largest depth of the tiles under that rectangle (4 pixels
@@ -1725,6 +1743,10 @@ constexpr int KFH_PLAN_COARSE_CELLS = KFH_PLAN_MAX_TILES / 16 + 64;
 // decides: the smallest power of two that brings the expected number of items down to target_items.
 __device__ inline int integrate_group_size(const IntegrateArgs &a) {
     const unsigned last = a.totals ? (unsigned)a.totals[3] : 0u;     // only the work launch writes it: stable here
+    // No earlier launch to go by (a context's first integration, or a caller without running totals): the longest
+    // runs.  Guessing "dense" for a sparse frame costs that one launch some wavefronts; guessing "sparse" for a dense
+    // volume makes every box replay its column (three times the launch's time).
+    if (last == 0u) return 32;
     // at least half of the volume was visited: the longest runs leave nothing to replay and still make more items
     // than the device has wavefront slots to fill
     if (last >= (unsigned)(a.gx * a.gy) * (unsigned)a.gz / 2u) return 32;
@@ -1823,6 +1845,230 @@ __global__ __launch_bounds__(256) void k_integrate_plan(IntegrateArgs a) {
     }
 }
 
+// -----------------------------------------------------------------------------------------------------
+// The march of a work item that lies wholly inside the image (and more than mu in front of the camera), with TWO
+// x-adjacent columns per lane: voxels are read and written 8 bytes per lane (a dword per lane does not reach 60 % of
+// the memory system's rate in this traversal whatever the arithmetic; 8 bytes do), and everything the two columns
+// evaluate alike runs as packed f32 instructions.  The 256 columns of a box then need 128 lanes, so a block's
+// wavefronts 0-1 march the first half of the item's planes and wavefronts 2-3 the second half.
+//
+// The planes are taken V2U at a time: a batch's voxels are requested first (their addresses need no arithmetic), then
+// its positions are advanced and projected and its depth pixels requested, the batch is updated in registers and
+// stored - loads and stores each in one burst.
+//
+// Per voxel the results are the reference's: the positions are its running sums (one IEEE addition per component and
+// plane), the pixel comes from the correctly rounded quotients (shared-reciprocal division, here on packed pairs),
+// and the update either takes the free-space shortcut on the raw word (value 32766 stays, weight + 1 capped) or the
+// reference's expression sequence.
+// -----------------------------------------------------------------------------------------------------
+#ifndef KFH_INTEGRATE_V2U
+#define KFH_INTEGRATE_V2U 8
+#endif
+constexpr int V2U = KFH_INTEGRATE_V2U;      // planes per batch of the two-column march
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+__device__ inline v2f pk_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ inline v2f splat2(float v) { return v2f{v, v}; }
+// the two quotients n.x / d and n.y / d, each bit-identical to IEEE division (div_shared on a packed pair)
+__device__ inline v2f div_shared2(v2f n, float d, float r1) {
+    const v2f dd = splat2(-d), rr = splat2(r1);
+    const v2f q0 = n * rr;
+    const v2f q1 = pk_fma(pk_fma(dd, q0, n), rr, q0);
+    return pk_fma(pk_fma(dd, q1, n), rr, q1);
+}
+
+struct Columns2 {            // running sums of the columns x (A) and x + 1 (B)
+    v2f pxyA, pxyB;          // volume-to-camera position, x and y
+    v2f cxyA, cxyB;          // K * position, x and y
+    v2f pz, cz;              // z of both: {A, B}
+};
+
+// The reference's update of one voxel outside the free-space shortcut: `dz` = depth - camera z, (px, py, pz) the
+// voxel in camera space.  Returns the raw word to store (the old one when the voxel stays untouched).
+__device__ inline unsigned integrate_update_general(unsigned rawword, float dz, float px, float py, float pz, float mu,
+                                                    float maxweight) {
+    if (dz <= -mu) return rawword;
+    float sdf = 1.f;
+    if (dz < mu) {
+        const float r1 = refined_rcp(pz);
+        const float rx = div_shared(px, pz, r1), ry = div_shared(py, pz, r1);
+        const float diff = dz * sqrtf(1 + rx * rx + ry * ry);
+        if (!(diff > -mu)) return rawword;
+        sdf = fminf(1.f, diff / mu);
+    }
+    const short rx16 = (short)(rawword & 0xFFFFu), ry16 = (short)(rawword >> 16);
+    float tsdf = (float)rx16 * KFH_SHORT2FLOAT;
+    float wgt = (float)ry16;
+    tsdf = fmaxf(-1.f, fminf((wgt * tsdf + sdf) / (wgt + 1), 1.f));
+    wgt = fminf(wgt + 1, maxweight);
+    return ((unsigned)(unsigned short)(short)(tsdf * KFH_FLOAT2SHORT)) | ((unsigned)(unsigned short)(short)wgt << 16);
+}
+
+__device__ inline void integrate_clear_marks(const IntegrateArgs &a, int x, int y, int z) {
+    const int ex = ((x & 7) == 0 && x > 0) ? 1 : 0, ey = ((y & 7) == 0 && y > 0) ? 1 : 0;
+    const int ez = ((z & 7) == 0 && z > 0) ? 1 : 0;
+    for (int iz = 0; iz <= ez; ++iz)
+        for (int iy = 0; iy <= ey; ++iy)
+            for (int ix = 0; ix <= ex; ++ix)
+                a.bricks[((x >> 3) - ix) + a.bgx * (((y >> 3) - iy) + a.bgy * ((z >> 3) - iz))] = 0;
+}
+
+// One wavefront's share of an inside-the-image item: columns (x, x + 1) of row y, planes of the item's boxes clipped
+// to [zlo, zhi).  Returns the number of voxels it stored (diagnostics).
+__device__ inline unsigned integrate_item_inside2(const IntegrateArgs &a, const Mat4 &invTrack, const Mat4 &K, f3 delta,
+                                                  f3 cameraDelta, int x, int y, int first_bz, unsigned item_mask,
+                                                  int zlo, int zmid, int zhi, bool upper_first) {
+    const int sx = a.sx, sy = a.sy, sz = a.sz;
+    const float mu = a.mu;
+    const bool in_vol = x < sx && y < sy;                  // sx is even: x + 1 < sx as well
+    const unsigned col = ((unsigned)min(x, sx - 2) + (unsigned)min(y, sy - 1) * (unsigned)sx) * (unsigned)sizeof(short2);
+    const unsigned plane_bytes = (unsigned)sx * (unsigned)sy * (unsigned)sizeof(short2);     // at most 2^26
+    // depth pixels through a buffer descriptor: an index past the image reads 0 (no depth), whatever the lane holds
+    const __amdgpu_buffer_rsrc_t depth_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.depth), 0, a.w * a.h * (int)sizeof(float), 0x00020000);
+    const unsigned row_bytes = (unsigned)a.w * 4u;
+    const unsigned capword = ((unsigned)(int)a.maxweight << 16) | 32766u;   // checked by the host: 0 <= maxweight <= 32767
+
+    auto start_sums = [&](Columns2 &c) {
+        const float py = ((float)y + 0.5f) * a.dimy / (float)sy, pz = (0.0f + 0.5f) * a.dimz / (float)sz;
+        const f3 posA = xform(invTrack, mk3(((float)x + 0.5f) * a.dimx / (float)sx, py, pz));
+        const f3 posB = xform(invTrack, mk3(((float)(x + 1) + 0.5f) * a.dimx / (float)sx, py, pz));
+        const f3 camA = xform(K, posA), camB = xform(K, posB);
+        c.pxyA = v2f{posA.x, posA.y}; c.pxyB = v2f{posB.x, posB.y};
+        c.cxyA = v2f{camA.x, camA.y}; c.cxyB = v2f{camB.x, camB.y};
+        c.pz = v2f{posA.z, posB.z}; c.cz = v2f{camA.z, camB.z};
+    };
+    const v2f dpxy = {delta.x, delta.y}, dcxy = {cameraDelta.x, cameraDelta.y};
+    const v2f dpz = splat2(delta.z), dcz = splat2(cameraDelta.z);
+    auto advance = [&](Columns2 &c) {
+        c.pxyA += dpxy; c.pxyB += dpxy;
+        c.cxyA += dcxy; c.cxyB += dcxy;
+        c.pz += dpz; c.cz += dcz;
+    };
+
+    Columns2 c;
+    start_sums(c);
+    int zacc = 0;                                  // the sums hold the state of plane zacc
+    unsigned written = 0;
+
+    // A batch of V2U planes: slot u holds the voxels, the depth pixels and the camera z of one plane.
+    uint2 raw[V2U], out[V2U];
+    v2f dpix[V2U], camz[V2U];
+    v2f sA, sB, sZ;          // position sums at the batch's first plane (only the band near a surface needs positions:
+                             //   they are re-derived from here)
+    int ze = 0;              // end of the run being marched
+
+    // Voxels go through a buffer descriptor that starts at the batch's first plane: a plane is a scalar offset and the
+    // column a 32-bit lane offset, so no lane computes a 64-bit address.
+    typedef unsigned v2u __attribute__((ext_vector_type(2)));
+    __amdgpu_buffer_rsrc_t vol_rsrc;
+    auto open_batch = [&](int zi) {
+        vol_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            reinterpret_cast<char *>(a.vol) + (size_t)(zi - a.z0) * plane_bytes, 0, (int)(V2U * plane_bytes), 0x00020000);
+    };
+    // request the voxels of the u-th plane of the batch at zi (a plane past the end of the run is never stored: its
+    // load re-reads the run's last plane)
+    auto request = [&](int u, int zi) {
+        const v2u v = __builtin_amdgcn_raw_buffer_load_b64(vol_rsrc, col, (unsigned)min(u, ze - 1 - zi) * plane_bytes, 0);
+        raw[u] = make_uint2(v.x, v.y);
+    };
+    // project the plane the sums stand at into slot u, request its depth pixels, advance the sums
+    auto project = [&](int u) {
+        camz[u] = c.cz;
+        const v2f r0 = {__builtin_amdgcn_rcpf(c.cz.x), __builtin_amdgcn_rcpf(c.cz.y)};
+        const v2f r1 = pk_fma(pk_fma(-c.cz, r0, splat2(1.f)), r0, r0);          // refined_rcp of both
+        const v2f pfA = div_shared2(c.cxyA, c.cz.x, r1.x) + splat2(0.5f);
+        const v2f pfB = div_shared2(c.cxyB, c.cz.y, r1.y) + splat2(0.5f);
+        // (24-bit multiply: the row is below 2^16 and a row's bytes below 2^24, checked by the host)
+        const unsigned offA = ((unsigned)pfA.x << 2) + __umul24((unsigned)pfA.y, row_bytes);
+        const unsigned offB = ((unsigned)pfB.x << 2) + __umul24((unsigned)pfB.y, row_bytes);
+        dpix[u] = v2f{__builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(depth_rsrc, offA, 0, 0)),
+                      __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(depth_rsrc, offB, 0, 0))};
+        advance(c);
+    };
+    // update plane z from slot u (the plane is the u-th of its batch); the new words go to out[u]
+    auto update = [&](int u, int z) {
+        const v2f dz = dpix[u] - camz[u];
+        const unsigned rawA = raw[u].x, rawB = raw[u].y;
+        // free space seen as free space again: 32766 * KFH_SHORT2FLOAT is exactly 1.0f, so the reference's
+        // (w * 1 + 1) / (w + 1) is 1 for every weight w >= 0 and only the weight moves
+        const bool freeA = dz.x >= mu, freeB = dz.y >= mu;
+        const bool plainA = (rawA & 0x8000FFFFu) == 32766u, plainB = (rawB & 0x8000FFFFu) == 32766u;
+        unsigned outA = (freeA & plainA) ? min(rawA + 0x10000u, capword) : rawA;
+        unsigned outB = (freeB & plainB) ? min(rawB + 0x10000u, capword) : rawB;
+        // everything else that the reference touches: the band around the surface (-mu < dz < mu), and free space
+        // over a voxel that has seen a surface.  (dz <= -mu: behind the surface, untouched; a pixel without depth
+        // has dz = -camz < -mu, as the plan launch only calls an item inside when it lies beyond mu.)
+        const bool slowA = (__builtin_fabsf(dz.x) < mu) | (freeA & !plainA);
+        const bool slowB = (__builtin_fabsf(dz.y) < mu) | (freeB & !plainB);
+        if (slowA | slowB) {
+            v2f pxyA = sA, pxyB = sB, pz = sZ;
+#pragma unroll
+            for (int k = 0; k < u; ++k) { pxyA += dpxy; pxyB += dpxy; pz += dpz; }
+            if (slowA) outA = integrate_update_general(rawA, dz.x, pxyA.x, pxyA.y, pz.x, mu, a.maxweight);
+            if (slowB) outB = integrate_update_general(rawB, dz.y, pxyB.x, pxyB.y, pz.y, mu, a.maxweight);
+            if (a.bricks && in_vol && z < ze) {
+                if ((short)rawA >= RAY_COARSE_SAFE && (short)outA < RAY_COARSE_SAFE) integrate_clear_marks(a, x, y, z);
+                if ((short)rawB >= RAY_COARSE_SAFE && (short)outB < RAY_COARSE_SAFE) integrate_clear_marks(a, x + 1, y, z);
+            }
+        }
+        out[u] = make_uint2(outA, outB);
+    };
+    auto store = [&](int u, int z) {
+        // free space seen often enough stays at (1, maxweight): nothing to store then
+        if (in_vol & (z < ze) & ((out[u].x != raw[u].x) | (out[u].y != raw[u].y))) {
+            __builtin_amdgcn_raw_buffer_store_b64(v2u{out[u].x, out[u].y}, vol_rsrc, col, (unsigned)u * plane_bytes, 0);
+            if (KFH_STAMPS_COMPILED) written += (out[u].x != raw[u].x) + (out[u].y != raw[u].y);
+        }
+    };
+
+    // The planes [zlo, zhi) are taken as two segments, [zlo, zmid) and [zmid, zhi); with `upper_first` the upper one
+    // comes first (its sums are reached by replaying the additions, and the lower one starts over from plane 0).
+    // A launch that starts with the planes the launch before it touched last finds part of them in the memory-side
+    // cache, which holds about half of a 512^3 volume.
+    for (int pass = 0; pass < 2; ++pass) {
+    const bool upper = (pass == 0) == upper_first;
+    const int clo = upper ? zmid : zlo, chi = upper ? zhi : zmid;
+    unsigned mask = item_mask;
+    while (mask) {
+        // a run of boxes that follow each other without a gap
+        const int k0 = __ffs(mask) - 1;
+        const unsigned above = ~(mask >> k0);
+        const int len = above ? __ffs(above) - 1 : 32 - k0;
+        mask &= ~((len >= 32 ? ~0u : ((1u << len) - 1u)) << k0);
+        const int zs = max(max(clo, a.z0), (first_bz + k0) * a.zchunk);
+        ze = min(min(chi, a.z1), (first_bz + k0 + len) * a.zchunk);
+        if (zs >= ze) continue;
+        if (zacc > zs) {              // the previous run left the sums past this run's start
+            start_sums(c);
+            zacc = 0;
+        }
+#pragma unroll 4
+        for (int z = zacc; z < zs; ++z) advance(c);
+        // Per batch of V2U planes the memory operations go out in bursts (stores and loads interleaved with the
+        // arithmetic plane by plane move the same bytes more slowly): the voxel loads back to back, then the
+        // projections with the depth loads, the updates in registers, and the stores back to back.
+        for (int zi = zs; zi < ze; zi += V2U) {
+            open_batch(zi);
+#pragma unroll
+            for (int u = 0; u < V2U; ++u) request(u, zi);
+            __builtin_amdgcn_sched_barrier(0);
+            sA = c.pxyA; sB = c.pxyB; sZ = c.pz;
+#pragma unroll
+            for (int u = 0; u < V2U; ++u) project(u);
+#pragma unroll
+            for (int u = 0; u < V2U; ++u) update(u, zi + u);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < V2U; ++u) store(u, zi + u);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        zacc = zs + (ze - zs + V2U - 1) / V2U * V2U;
+    }
+    }
+    return written;
+}
+
 // Second launch: a workgroup takes boxes from the list; one thread per (x, y) column of the box.
 __global__ __launch_bounds__(256, KFH_INTEGRATE_MIN_WAVES) void k_integrate(IntegrateArgs a) {
     if (!KFH_STAMPS_COMPILED) a.dbg = nullptr;      // per-wavefront statistics only in diagnostic builds
@@ -1837,6 +2083,8 @@ __global__ __launch_bounds__(256, KFH_INTEGRATE_MIN_WAVES) void k_integrate(Inte
         }
     }
     if (nbox == 0) return;
+    // launches with an open gate so far (the plan launch has counted this one): odd or even
+    const bool launch_parity = a.totals ? (__builtin_amdgcn_readfirstlane((unsigned)a.totals[1]) & 1u) != 0u : false;
     // diagnostics (dbg != null): per box and wavefront {start, end} of the 100 MHz counter, candidates, written
     const Mat4 invTrack = *a.inv_track;
     const int sx = a.sx, sy = a.sy, sz = a.sz, w = a.w;
@@ -1855,8 +2103,49 @@ __global__ __launch_bounds__(256, KFH_INTEGRATE_MIN_WAVES) void k_integrate(Inte
         const int bx = item.x & 0xFF, by = (item.x >> 8) & 0xFFF, first_bz = (item.x >> 20) & 0xFF;
         unsigned group_mask = item.y;
         const bool item_inside = (item.x >> 28) & 1u;
-        const int x = bx * 64 + (threadIdx.x & 63);
-        const int y = by * 4 + (threadIdx.x >> 6);
+        if (a.vec2 && item_inside) {
+            // two columns per lane: wavefronts 0-1 take the rows of the item's first planes, wavefronts 2-3 those of
+            // the rest (split between two boxes; a single box is split in the middle)
+            const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+            const unsigned imask = __builtin_amdgcn_readfirstlane(group_mask);
+            const int ifirst = __builtin_amdgcn_readfirstlane(first_bz);
+            const int nboxes = __popc(imask);
+            int zsplit;
+            if (nboxes >= 2) {
+                unsigned m = imask;
+                for (int i = 0; i < (nboxes + 1) / 2; ++i) m &= m - 1u;
+                zsplit = (ifirst + __ffs(m) - 1) * a.zchunk;
+            } else {
+                const int bz = ifirst + __ffs(imask) - 1;
+                const int zc0 = max(a.z0, bz * a.zchunk), zc1 = min(a.z1, (bz + 1) * a.zchunk);
+                zsplit = zc0 + ((zc1 - zc0 + 1) / 2 + V2U - 1) / V2U * V2U;
+            }
+            const bool second = wv >= 2;
+            // each of the two takes its planes as two segments (split at a box boundary; short items are not split),
+            // in an order that alternates from launch to launch
+            const int span_lo = max(a.z0, (ifirst + __ffs(imask) - 1) * a.zchunk);
+            const int span_hi = min(a.z1, (ifirst + 32 - __clz(imask)) * a.zchunk);
+            const int zlo = second ? max(zsplit, span_lo) : span_lo, zhi = second ? span_hi : min(zsplit, span_hi);
+            const int zmid = zhi - zlo >= 4 * a.zchunk ? zlo + (zhi - zlo) / (2 * a.zchunk) * a.zchunk : zhi;
+            const unsigned stored =
+                integrate_item_inside2(a, invTrack, K, delta, cameraDelta, bx * BOX_X + (lane % (BOX_X / 2)) * 2,
+                                       by * BOX_Y + (wv & 1) * (BOX_Y / 2) + lane / (BOX_X / 2), ifirst, imask,
+                                       zlo, zmid, zhi, launch_parity);
+            if (a.dbg) {
+                unsigned long long tot = stored;
+                for (int m = 32; m >= 1; m >>= 1) tot += __shfl_xor(tot, m, 64);
+                if (lane == 0) {
+                    unsigned long long *d = a.dbg + ((size_t)bi * 4 + wv) * 4;
+                    d[0] = dbg_t0;
+                    d[1] = __builtin_amdgcn_s_memrealtime();
+                    d[2] = 0;
+                    d[3] = tot;
+                }
+            }
+            continue;
+        }
+        const int x = bx * BOX_X + ((int)threadIdx.x & (BOX_X - 1));
+        const int y = by * BOX_Y + (int)threadIdx.x / BOX_X;
         const bool in_vol = x < sx && y < sy;
         const f3 p0 = mk3(((float)x + 0.5f) * dimx / (float)sx, ((float)y + 0.5f) * dimy / (float)sy,
                           (0.0f + 0.5f) * dimz / (float)sz);
@@ -2053,13 +2342,13 @@ static int integrate_target_items() {
     return forced > 0 ? forced : 4096;
 }
 
-int integrate_box_voxels(int z1) { return 64 * 4 * integrate_zchunk(z1); }
+int integrate_box_voxels(int z1) { return BOX_X * BOX_Y * integrate_zchunk(z1); }
 
 size_t integrate_box_list_bytes(const int res[3], int z1) {
     const int zchunk = integrate_zchunk(z1);
     // an item holds at least min_group boxes' worth of z range
     const int g = integrate_min_group(z1);
-    return (size_t)((res[0] + 63) / 64) * ((res[1] + 3) / 4) * (((z1 + zchunk - 1) / zchunk + g - 1) / g) * sizeof(uint2);
+    return (size_t)((res[0] + BOX_X - 1) / BOX_X) * ((res[1] + BOX_Y - 1) / BOX_Y) * (((z1 + zchunk - 1) / zchunk + g - 1) / g) * sizeof(uint2);
 }
 
 hipError_t launch_integrate(short2 *vol, const int res[3], const float dim[3], int z0, int z1,
@@ -2077,7 +2366,7 @@ hipError_t launch_integrate(short2 *vol, const int res[3], const float dim[3], i
     a.depth = depth; a.w = w; a.h = h;
     a.inv_track = inv_track; a.K = K; a.mu = mu; a.maxweight = maxweight; a.gate = gate;
     a.zchunk = integrate_zchunk(z1);
-    a.gx = (res[0] + 63) / 64; a.gy = (res[1] + 3) / 4; a.gz = (z1 + a.zchunk - 1) / a.zchunk;
+    a.gx = (res[0] + BOX_X - 1) / BOX_X; a.gy = (res[1] + BOX_Y - 1) / BOX_Y; a.gz = (z1 + a.zchunk - 1) / a.zchunk;
     a.boxes = static_cast<uint2 *>(boxes); a.box_count = box_count;
     a.list_capacity = (unsigned)(integrate_box_list_bytes(res, z1) / sizeof(uint2));
     a.min_group = integrate_min_group(z1); a.target_items = integrate_target_items();
@@ -2085,11 +2374,15 @@ hipError_t launch_integrate(short2 *vol, const int res[3], const float dim[3], i
     a.tile_max = tile_max; a.tiles_x = (w + PRE_TX - 1) / PRE_TX; a.tiles_y = (h + PRE_TY - 1) / PRE_TY;
     a.totals = totals;
     a.dbg = g_integrate_debug;
+    static const bool vec2_enabled = !(std::getenv("KFH_INTEGRATE_VEC2") && std::atoi(std::getenv("KFH_INTEGRATE_VEC2")) == 0);
+    a.vec2 = vec2_enabled && (res[0] & 1) == 0 && (reinterpret_cast<uintptr_t>(vol) & 7u) == 0 && maxweight >= 0.f &&
+             maxweight <= 32767.f && (long long)w * h * 4 < (1ll << 31) && w < (1 << 22) && h < (1 << 16);
     if (a.gx > 256 || a.gy > 4096 || a.gz > 256) return hipErrorInvalidValue;   // packed item
     // the plan launch decides its group size itself (1 to 32 lanes per work item): threads for the widest layout
     const int plan_threads = a.gx * a.gy * ((a.gz + 31) / 32) * 32;
     const int nitems = a.gx * a.gy * ((a.gz + a.min_group - 1) / a.min_group);
-    const dim3 plan_grid((plan_threads + 255) / 256), work_grid(nitems < 2048 ? nitems : 2048);
+    static const int work_blocks = std::getenv("KFH_INTEGRATE_BLOCKS") ? std::atoi(std::getenv("KFH_INTEGRATE_BLOCKS")) : 2048;
+    const dim3 plan_grid((plan_threads + 255) / 256), work_grid(nitems < work_blocks ? nitems : work_blocks);
     hipLaunchKernelGGL(k_integrate_plan, plan_grid, dim3(256), 0, s, a);
     hipLaunchKernelGGL(k_integrate, work_grid, dim3(256), 0, s, a);
     return hipGetLastError();
