@@ -154,16 +154,25 @@ def spawn_ranks(a):
     return subprocess.call(cmd, env=env)
 
 
-def dense_integrate_leg(KFusion, KFusionConfig, intrinsics, V, torch):
-    """Integration of a volume whose EVERY voxel is updated: a 0.5 m cube that lies wholly inside the camera frustum,
-    one metre in front of the camera, with the seen surface (a flat wall at 3 m) far behind it.  The first four frames
-    of a sequence integrate unconditionally from the initial pose, so each of them reads and writes all V^3 voxels
-    (8 B each: the weight changes every time); timed with HIP events on the pipeline's stream like the main leg."""
+def dense_integrate_leg(KFusion, KFusionConfig, intrinsics, V, torch, band=False):
+    """Integration of a volume whose EVERY voxel is updated: a cube that lies wholly inside the camera frustum, one
+    metre in front of the camera, in front of a flat wall.  The first four frames of a sequence integrate
+    unconditionally from the initial pose, so each of them reads and writes all V^3 voxels (8 B each: the weight
+    changes every time); timed with HIP events on the pipeline's stream like the main leg.
+
+    band=False: a 0.5 m cube with the wall at 3 m, far behind it: every voxel is free space (the cheapest update: the
+    value stays 1, the weight moves).  band=True: the volume is a 0.17 m thick slab around a wall at 1.1 m, so every
+    voxel lies inside the truncation band (|depth - z| < mu = 0.1 m) and takes the reference's full update: the ray
+    scale with its square root and two divisions, and the running average with a third."""
+    if band:
+        size, direction, wall_mm = (0.5, 0.5, 0.17), (0.25, 0.25, -1.015), 1100
+    else:
+        size, direction, wall_mm = (0.5, 0.5, 0.5), (0.25, 0.25, -1.0), 3000
     cfg = KFusionConfig(input_size=(640, 480), intrinsics=intrinsics, volume_resolution=(V, V, V),
-                        volume_size=(0.5, 0.5, 0.5), volume_direction=(0.25, 0.25, -1.0))
+                        volume_size=size, volume_direction=direction)
     kf = KFusion(cfg)
     kf.set_timing(2)
-    wall = torch.full((480, 640), 3000, dtype=torch.int16, device="cuda")
+    wall = torch.full((480, 640), wall_mm, dtype=torch.int16, device="cuda")
     ms, boxes = [], []
     for rep in range(4):
         if rep:
@@ -180,18 +189,25 @@ def dense_integrate_leg(KFusion, KFusionConfig, intrinsics, V, torch):
     vox = float(np.mean(boxes))
     assert vox >= V ** 3, "the plan must keep every box of the dense volume (%g of %g voxels)" % (vox, V ** 3)
     from slambench_amd import native
-    weights = kf.download(native.BUF_VOLUME)[..., 1]
+    volume = kf.download(native.BUF_VOLUME)
+    weights = volume[..., 1]
     assert int(weights.min()) == 4 and int(weights.max()) == 4, "every voxel must have been updated by every frame"
+    if band:
+        assert int(np.abs(volume[..., 0].astype(np.int32)).max()) < 32766, "every voxel must lie inside the truncation band"
     kf.close()
-    t = float(np.median(ms)) * 1e-3
+    t, tm = float(np.median(ms)) * 1e-3, float(np.mean(ms)) * 1e-3
+    what = ("%d^3 voxels over a 0.5 x 0.5 x 0.17 m slab around a wall at 1.1 m: every voxel inside the truncation band "
+            "(checked: every weight == number of frames, no value at +-1)" % V) if band else \
+           ("%d^3 voxels over a 0.5 m cube inside the frustum, wall at 3 m: all voxels read and written "
+            "(checked: every weight == number of frames)" % V)
     return {"kernel": "k_integrate_plan + k_integrate", "bound": "hbm", "achieved": 8.0 * V ** 3 / t / 1e9,
-            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": 8.0 * V ** 3 / t / 1e9 / HBM_PEAK_GBS, "traffic": None,
-            "ms_per_launch": t * 1e3, "ms_per_launch_mean": float(np.mean(ms)), "launches_timed": len(ms),
+            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": 8.0 * V ** 3 / t / 1e9 / HBM_PEAK_GBS,
+            "frac_mean": 8.0 * V ** 3 / tm / 1e9 / HBM_PEAK_GBS, "traffic": None,
+            "ms_per_launch": t * 1e3, "ms_per_launch_mean": tm * 1e3, "launches_timed": len(ms),
             "gvox_per_s": V ** 3 / t / 1e9,
-            "note": "median: the first integration of a sequence has no previous box count to size its work items by and "
-                    "takes single boxes (slower on a dense volume); the mean includes those launches",
-            "workload": "%d^3 voxels over a 0.5 m cube inside the frustum, wall at 3 m: all voxels read and written "
-                        "(checked: every weight == number of frames), 8 B x V^3 per launch, median HIP-event duration" % V}
+            "note": "frac from the median, frac_mean from the mean of the HIP-event durations (plan + work launch) of "
+                    "the timed integrations",
+            "workload": what + ", 8 B x V^3 per launch"}
 
 
 def main():
@@ -431,6 +447,8 @@ def main():
         }
         if not a.no_dense_leg and not zslab and world == 1:
             result["roofline_dense"] = dense_integrate_leg(KFusion, KFusionConfig, TUM_FR1_DEPTH_INTRINSICS, V, torch)
+            result["roofline_dense_band"] = dense_integrate_leg(KFusion, KFusionConfig, TUM_FR1_DEPTH_INTRINSICS, V,
+                                                                torch, band=True)
             dense = result["roofline_dense"]
             if os.path.exists(a.dense_traffic_json):
                 try:

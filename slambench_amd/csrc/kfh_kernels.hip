@@ -1812,13 +1812,23 @@ __global__ __launch_bounds__(256) void k_integrate_plan(IntegrateArgs a) {
         keep = cls != 0;
         edge = cls == 1;
     }
+    // List positions are handed out per workgroup: the wavefronts count their items in LDS and one lane adds the
+    // block's totals to the two list counters with ONE 64-bit atomic (and to the running box total with another).
+    // Every wavefront adding to the same words itself cost a dense volume's plan launch 18 us, most of it the
+    // 1536 atomics queueing on three addresses.
+    __shared__ unsigned blk_heavy, blk_light, blk_boxes, base_heavy, base_light;
+    if (threadIdx.x == 0) { blk_heavy = 0u; blk_light = 0u; blk_boxes = 0u; }
+    __syncthreads();
     const unsigned long long m = __ballot(keep);
+    const int lane = threadIdx.x & 63;
+    unsigned gm = 0u, ge = 0u, off_h = 0u, off_t = 0u;
+    unsigned long long heavy_mask = 0ull, light_mask = 0ull;
+    bool leader = false, heavy = false;
     if (m) {
-        const int lane = threadIdx.x & 63;
-        const unsigned gm = (unsigned)((m >> (lane & ~(G - 1))) & ((1ull << G) - 1ull));
+        gm = (unsigned)((m >> (lane & ~(G - 1))) & ((1ull << G) - 1ull));
         // an item whose surviving boxes are all of the "inside the image" kind says so (bit 28)
-        const unsigned ge = (unsigned)((__ballot(edge) >> (lane & ~(G - 1))) & ((1ull << G) - 1ull));
-        const bool leader = r == 0 && gm != 0u;
+        ge = (unsigned)((__ballot(edge) >> (lane & ~(G - 1))) & ((1ull << G) - 1ull));
+        leader = r == 0 && gm != 0u;
         const unsigned long long lm = __ballot(leader);
         const int first = __ffsll((long long)lm) - 1;
         // An item's cost grows with the planes it marches and, more slowly, with the planes it replays first.  Items in
@@ -1826,22 +1836,32 @@ __global__ __launch_bounds__(256) void k_integrate_plan(IntegrateArgs a) {
         // the work launch takes the front first.
         // (a marched plane costs about sixteen replayed ones; single-box items all cost the same: they keep their order)
         const int cost = __popc(gm) * a.zchunk * 16 + g * G * a.zchunk;
-        const bool heavy = leader && (G == 1 || 2 * cost >= G * a.zchunk * 16 + a.gz * a.zchunk);
-        const unsigned long long hm = __ballot(heavy), tm = lm & ~hm;
-        unsigned base_h = 0, base_t = 0;
+        heavy = leader && (G == 1 || 2 * cost >= G * a.zchunk * 16 + a.gz * a.zchunk);
+        heavy_mask = __ballot(heavy);
+        light_mask = lm & ~heavy_mask;
         if (lane == first) {
-            if (hm) base_h = atomicAdd(a.box_count, (unsigned)__popcll(hm));
-            if (tm) base_t = atomicAdd(a.box_count + 1, (unsigned)__popcll(tm));
-            if (a.totals) atomicAdd(a.totals, (unsigned long long)__popcll(m));
+            if (heavy_mask) off_h = atomicAdd(&blk_heavy, (unsigned)__popcll(heavy_mask));
+            if (light_mask) off_t = atomicAdd(&blk_light, (unsigned)__popcll(light_mask));
+            atomicAdd(&blk_boxes, (unsigned)__popcll(m));
         }
-        base_h = __builtin_amdgcn_readlane(base_h, first);
-        base_t = __builtin_amdgcn_readlane(base_t, first);
-        if (leader) {
-            const unsigned long long below = (1ull << lane) - 1ull;
-            const unsigned at = heavy ? base_h + __popcll(hm & below) : a.list_capacity - 1u - (base_t + __popcll(tm & below));
-            a.boxes[at] =
-                make_uint2((unsigned)bx | ((unsigned)by << 8) | ((unsigned)(g * G) << 20) | (ge == 0u ? 1u << 28 : 0u), gm);
-        }
+        off_h = __builtin_amdgcn_readlane(off_h, first);
+        off_t = __builtin_amdgcn_readlane(off_t, first);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && blk_boxes != 0u) {
+        const unsigned long long old =
+            atomicAdd(reinterpret_cast<unsigned long long *>(a.box_count), ((unsigned long long)blk_light << 32) | blk_heavy);
+        if (a.totals) atomicAdd(a.totals, (unsigned long long)blk_boxes);
+        base_heavy = (unsigned)old;
+        base_light = (unsigned)(old >> 32);
+    }
+    __syncthreads();
+    if (leader) {
+        const unsigned long long below = (1ull << lane) - 1ull;
+        const unsigned at = heavy ? base_heavy + off_h + __popcll(heavy_mask & below)
+                                  : a.list_capacity - 1u - (base_light + off_t + __popcll(light_mask & below));
+        a.boxes[at] =
+            make_uint2((unsigned)bx | ((unsigned)by << 8) | ((unsigned)(g * G) << 20) | (ge == 0u ? 1u << 28 : 0u), gm);
     }
 }
 
