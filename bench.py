@@ -74,6 +74,13 @@ def parse_args():
     ap.add_argument("--force-exchange", action="store_true",
                     help="--mode zslab on ONE rank: still take the exchange path (slab march, all-gather, composite, "
                          "all-reduce) through a single-rank RCCL group, to time the collectives' fixed cost")
+    ap.add_argument("--zslab-volume", type=int, default=2048,
+                    help="N>1, replicas: TSDF resolution of the additional z-slab leg (BASELINE.json configs[3]: ONE "
+                         "sequence whose 2048^3 volume is sharded over the ranks), reported under zslab_<volume>")
+    ap.add_argument("--zslab-steps", type=int, default=100, help="timed frames of the additional z-slab leg")
+    ap.add_argument("--no-zslab-leg", action="store_true", help="N>1, replicas: skip the additional z-slab leg")
+    ap.add_argument("--pg-timeout", type=float, default=180.0,
+                    help="seconds after which a collective that does not complete ends the run (non-zero exit)")
     ap.add_argument("--dense-traffic-json", default=os.path.join(ROOT, "profiles", "r2_dense_integrate.json"),
                     help="counter bytes of the dense integration leg (tools/make_profiles.py --dense)")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "integrate_traffic.json"),
@@ -210,6 +217,90 @@ def dense_integrate_leg(KFusion, KFusionConfig, intrinsics, V, torch, band=False
             "workload": what + ", 8 B x V^3 per launch"}
 
 
+def reduce_ranks(values, op, dist, torch, backend, world):
+    """All-reduce a short list of floats over the ranks (sum or max); a world of one returns them as they are."""
+    if world <= 1:
+        return [float(v) for v in values]
+    t = torch.tensor([float(v) for v in values], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.SUM if op == "sum" else dist.ReduceOp.MAX)
+    return [float(v) for v in t.tolist()]
+
+
+def zslab_leg(a, rank, world, dist, torch, backend, V, steps, solo=False):
+    """BASELINE.json configs[3] in the ranks of this run: ONE synthetic 640x480 sequence whose V^3 volume is sharded
+    into z-slabs over the ranks (integration per slab, per-slab ray segments exchanged and composited, ICP sums
+    replicated or all-reduced).  Every rank returns the same record: frames/s of the job, voxel updates per second
+    summed over the ranks, and the integrate roofline with boxes summed and launch time maximised over the ranks."""
+    from slambench_amd import synth
+    from slambench_amd.config import KFusionConfig, TUM_FR1_DEPTH_INTRINSICS
+    from slambench_amd.metrics import ate
+    from slambench_amd.sharded import SlabKFusion
+
+    cfg = KFusionConfig(input_size=(640, 480), intrinsics=TUM_FR1_DEPTH_INTRINSICS, volume_resolution=(V, V, V))
+    untimed = 8
+    total = steps + untimed
+    n_unique = max(8, min(40, total))
+    depth, gt, ts = synth.make_sequence(n_unique, seed=1, intrinsics=TUM_FR1_DEPTH_INTRINSICS, noise=True)
+    order = ping_pong(n_unique, total)
+    d_depth = torch.from_numpy(depth.view(np.int16)).cuda()
+    ptrs = [int(d_depth[i].data_ptr()) for i in range(n_unique)]
+    sharded = SlabKFusion(cfg, rank, world, dist, torch, icp=a.icp, force_exchange=solo, exchange=a.exchange)
+    kf = sharded.kf
+    kf.set_timing(2)                    # every integration of this short leg is timed
+    for i in range(untimed):
+        sharded.process_frame(ptrs[order[i]])
+    kf.sync()
+    boxes0, launches0, voxels_per_box = kf.integrate_totals()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(untimed, total):
+        sharded.process_frame(ptrs[order[i]])
+    kf.sync()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    boxes1, launches1, _ = kf.integrate_totals()
+    integ_ms, tracked = [], 0
+    for f in range(untimed, total):
+        st = kf.status(f)
+        tracked += int(st["tracked"])
+        if st["integrated"]:
+            integ_ms.append(float(kf.phase_ms(f)[2]))
+    n_int = launches1 - launches0
+    t_int = float(np.mean(integ_ms)) * 1e-3 if integ_ms else 0.0
+    n_fwd = min(total, n_unique)
+    est = np.stack([kf.status(f)["pose"] for f in range(n_fwd)])
+    ate_rmse = ate(est, gt[:n_fwd], ts[:n_fwd], ts[:n_fwd])["rmse"]
+    elapsed, t_int, neg_tracked = reduce_ranks([elapsed, t_int, -tracked], "max", dist, torch, backend, world)
+    (voxels,) = reduce_ranks([(boxes1 - boxes0) * voxels_per_box], "sum", dist, torch, backend, world)
+    sharded.close()
+    del d_depth
+    vox_per_launch = voxels / n_int if n_int else None
+    achieved = 8.0 * vox_per_launch / t_int / 1e9 if (n_int and t_int > 0) else None
+    return {
+        "workload": "ONE synthetic 640x480 sequence, %d^3 TSDF over 8 m in %d z-slabs, ICP 10/5/4, integration-rate 2 "
+                    "(BASELINE.json configs[3])" % (V, world),
+        "volume": V, "ranks": world, "backend": backend, "icp": a.icp,
+        "exchange": "all-gather of the packed ray segments" if a.exchange == "gather" else
+                    "all-to-all by image share + all-gather of the shares",
+        "steps": steps, "frames_per_s": steps / elapsed, "ms_per_step": elapsed / steps * 1e3,
+        "scaling": "strong",
+        "voxel_updates_per_s": voxels / elapsed,
+        "integrate_voxels_per_launch_all_ranks": vox_per_launch,
+        "integrate_ms_slowest_rank": t_int * 1e3 if t_int > 0 else None,
+        "tracked_fraction": -neg_tracked / max(1, steps),
+        "ate_rmse_m": ate_rmse,
+        "roofline": {"kernel": "k_integrate_plan + k_integrate", "bound": "hbm", "achieved": achieved,
+                     "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
+                     "frac": achieved / (HBM_PEAK_GBS * world) if achieved else None, "traffic": None,
+                     "note": "8 B x the voxels of the boxes the work launches of ALL ranks took per integration / the "
+                             "slowest rank's mean HIP-event duration of its two launches / (ranks x 8 TB/s)"},
+        "note": "frames/s of a sharded sequence is bounded by what every rank repeats (preprocessing, tracking); "
+                "voxel_updates_per_s is the figure that grows with the ranks",
+    }
+
+
 def main():
     a = parse_args()
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -245,7 +336,8 @@ def main():
             kw = {"device_id": torch.device("cuda", device_index)} if backend == "nccl" else {}
             if solo_exchange:
                 kw.update(init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1)
-            dist.init_process_group(backend, **kw)
+            import datetime
+            dist.init_process_group(backend, timeout=datetime.timedelta(seconds=a.pg_timeout), **kw)
             one = torch.ones(1, dtype=torch.int64, device="cuda" if backend == "nccl" else "cpu")
             dist.all_reduce(one)                   # the ranks count themselves (and the communicator comes up)
             ranks_seen = int(one.item())
@@ -362,8 +454,17 @@ def main():
     # Voxels the work launches of the timed region really had to read and write: the plan launch keeps the boxes
     # (64 x 4 x voxels_per_box / 256 voxels) that can hold a voxel integrateKernel would update; the device counts them.
     n_int = launches1 - launches0
-    vox_per_launch = (boxes1 - boxes0) * voxels_per_box / n_int if n_int else None
-    achieved = 8.0 * vox_per_launch / t_int / 1e9 if (integ_ms.size and n_int) else None
+    voxels_taken = (boxes1 - boxes0) * voxels_per_box
+    peak = HBM_PEAK_GBS
+    if zslab and world > 1:
+        # one volume over all ranks: boxes summed, launch time of the slowest rank, peak of all the GPUs
+        (voxels_taken,) = reduce_ranks([voxels_taken], "sum", dist, torch, backend, world)
+        (t_max,) = reduce_ranks([0.0 if np.isnan(t_int) else t_int], "max", dist, torch, backend, world)
+        t_int = t_max if t_max > 0 else float("nan")
+        planes = V
+        peak = HBM_PEAK_GBS * world
+    vox_per_launch = voxels_taken / n_int if n_int else None
+    achieved = 8.0 * vox_per_launch / t_int / 1e9 if (n_int and t_int == t_int and t_int > 0) else None
 
     # accuracy on the forward part of the stream (ground truth is known for the synthetic camera)
     n_fwd = min(total, n_unique)
@@ -413,7 +514,9 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": "KFusion 640x480 depth (TUM fr1 intrinsics), %d^3 TSDF over 8 m, ICP 10/5/4, "
-                            "integration-rate 2, synthetic room stream%s" % (V, " (configs[1])" if (V == 512 and a.csr == 1) else ""),
+                            "integration-rate 2, synthetic room stream%s"
+                            % (V, " (configs[3])" if (zslab and V == 2048) else
+                               " (configs[1])" if (V == 512 and a.csr == 1 and not zslab) else ""),
                 "compute_size": "%dx%d" % cfg.compute_size, "volume": V,
                 "input": "every depth frame is resident in HBM before the timed region starts (value has no upload in "
                          "it); pcie_inclusive_frames_per_s is the same stream with one host-to-device upload per frame",
@@ -423,8 +526,8 @@ def main():
                                 if zslab else "%d sequence(s) per rank (replicas, no collective; %s)" % (1 + len(extra), backend)
                                 if world > 1 else "%d sequence(s) on one GPU" % (1 + len(extra)) if extra else "single GPU"),
             },
-            "integrate_gvox_per_s": (V * V * planes / t_int / 1e9) if integ_ms.size else None,
-            "integrate_ms": t_int * 1e3 if integ_ms.size else None,
+            "integrate_gvox_per_s": (V * V * planes / t_int / 1e9) if t_int == t_int else None,
+            "integrate_ms": t_int * 1e3 if t_int == t_int else None,
             "integrate_voxels_per_launch": vox_per_launch,
             "integrate_visited_fraction": (vox_per_launch / (V * V * planes)) if vox_per_launch else None,
             "tracked_fraction": tracked / max(1, total - first),
@@ -434,9 +537,9 @@ def main():
                 "kernel": "k_integrate_plan + k_integrate",
                 "bound": "hbm",
                 "achieved": achieved,
-                "peak": HBM_PEAK_GBS,
+                "peak": peak,
                 "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS if achieved else None,
+                "frac": achieved / peak if achieved else None,
                 "traffic": traffic,
                 "traffic_source": traffic_source,
                 "note": "achieved = 8 B x the voxels of the boxes the work launch took (counted by the device; the plan "
@@ -492,11 +595,29 @@ def main():
     kf.close()
     for kq, _, _ in extra:
         kq.close()
+    del d_depth
+    leg_failed = False
+    if world > 1 and a.mode == "replicas" and not a.no_zslab_leg:
+        if rank == 0:       # should the sharded leg end the job, the replica line is at least in the log
+            sys.stderr.write("bench.py: replica leg done: " + json.dumps({k: result[k] for k in ("value", "n_gpus", "ms_per_step")}) + "\n")
+        torch.cuda.empty_cache()
+        try:
+            leg = zslab_leg(a, rank, world, dist, torch, backend, a.zslab_volume, a.zslab_steps)
+        except Exception as exc:            # the line still goes out, with the failure in it, and the run fails
+            leg_failed = True
+            leg = {"error": "%s: %s" % (type(exc).__name__, exc)}
+            sys.stderr.write("bench.py: rank %d: z-slab leg failed: %s\n" % (rank, leg["error"]))
+        if rank == 0:
+            result["zslab_%d" % a.zslab_volume] = leg
     if world > 1 or solo_exchange:
-        dist.barrier()
+        if not leg_failed:
+            dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(result))
+        sys.stdout.flush()
+    if leg_failed:
+        sys.exit(4)
     if ranks_seen != a.gpus:
         sys.stderr.write("bench.py: --gpus %d but %d rank(s) took part (WORLD_SIZE=%s)\n"
                          % (a.gpus, ranks_seen, os.environ.get("WORLD_SIZE")))

@@ -137,3 +137,31 @@ def test_device_side_collectives_on_a_single_rank_rccl_group(torch_cuda, tmp_pat
     assert ((r["normal"][..., 0] != -2) == hit).mean() > 0.999
     assert int(r["allreduce_calls"]) == 19 * frames
     kf.close()
+
+
+def test_bench_with_two_ranks_reports_the_replica_leg_and_the_zslab_leg(torch_cuda):
+    """`python bench.py --gpus 2` (the driver's multi-GPU command; two ranks on GPU 0 over gloo here): one JSON line
+    with the replica leg as `value` and the sharded leg of BASELINE.json's 8-GPU configuration under zslab_<volume>
+    (a small volume here), its boxes summed and its integrate time maximised over the ranks."""
+    import json
+    root = os.path.dirname(HERE)
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "24", "--warmup", "8",
+           "--no-cpu-baseline", "--no-host-frames", "--no-dense-leg", "--zslab-volume", "256", "--zslab-steps", "16",
+           "--unique-frames", "16"]
+    env = dict(os.environ, OMP_NUM_THREADS="4", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("WORLD_SIZE", None)
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, "exactly one JSON line: %r" % r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    leg = d["zslab_256"]
+    assert "error" not in leg, leg
+    assert leg["ranks"] == 2 and leg["volume"] == 256 and leg["scaling"] == "strong"
+    assert leg["frames_per_s"] > 0 and leg["voxel_updates_per_s"] > 0
+    assert leg["tracked_fraction"] == 1.0 and leg["ate_rmse_m"] < 0.01
+    roof = leg["roofline"]
+    assert roof["peak"] == 16000.0 and roof["achieved"] > 0 and 0 < roof["frac"] < 1
+    # both ranks' boxes are in the count: more voxels than one slab of the volume's frustum share alone could give
+    assert leg["integrate_voxels_per_launch_all_ranks"] > 0 and leg["integrate_ms_slowest_rank"] > 0
