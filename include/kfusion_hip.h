@@ -207,6 +207,33 @@ int kfh_composite_tile(kfh_context *ctx, const void *d_tn_parts, int n_parts, in
 typedef int (*kfh_allreduce_fn)(void *user, float *d_sums32, void *stream);
 int kfh_track_rows(kfh_context *ctx, int share, int share_count, kfh_allreduce_fn allreduce, void *user);
 
+/* ---- a group: z-slab sharding inside ONE process, driven by ONE thread; no counterpart in the reference ---- */
+/* The harness this library plugs into is a single process that calls the plugin frame by frame
+ * (framework/shared/src/SLAMBenchConfiguration.cpp:94-133 loads the libraries, :230-342 is the frame loop), so a
+ * plugin that wants to spread a large volume over the GPUs of a node cannot rely on one process per GPU.  A group
+ * holds one context per entry of `devices` (HIP device indices; an index may repeat, which puts several slabs on one
+ * device), gives member i the z-slab i of n (contiguous, nearly equal; kfh_config.slab_z0 / slab_z1 of `cfg` are
+ * ignored), and runs one sequence on all of them: every member preprocesses and tracks the whole frame (same inputs,
+ * same poses), integrates and marches only its slab, and composites the nearest hit per pixel straight out of every
+ * member's segment map - its own memory and its peers', read over the links after hipDeviceEnablePeerAccess; nothing
+ * is copied and no collective library is involved.  The devices order themselves by events; the calling thread only
+ * queues.  Results are those of kfh_raycast_slab + an all-gather + kfh_composite_slabs, bit for bit.
+ * A group of one member is a plain context.  At most 16 members; calls on one group must not overlap. */
+typedef struct kfh_group kfh_group;
+int kfh_group_create(const kfh_config *cfg, const int *devices, int n, kfh_group **out);
+int kfh_group_destroy(kfh_group *group);
+int kfh_group_reset(kfh_group *group);
+int kfh_group_size(kfh_group *group, int *n);
+/* member `index` as a context, for everything a group has no call of its own for (kfh_get_status, kfh_download,
+ * kfh_set_timing, ...).  Frame-stepping calls on a member (kfh_process_frame, kfh_end_frame, ...) break the group. */
+int kfh_group_member(kfh_group *group, int index, kfh_context **ctx);
+int kfh_group_upload_depth(kfh_group *group, const uint16_t *h_depth);      /* the same host frame to every member */
+/* d_depth_per_member[i]: the frame in the memory of member i's device */
+int kfh_group_set_depth_device(kfh_group *group, const uint16_t *const *d_depth_per_member);
+int kfh_group_process_frame(kfh_group *group);   /* Kfusion's four stages + the exchange, queued on every member */
+int kfh_group_sync(kfh_group *group);
+int kfh_group_get_pose(kfh_group *group, float pose[16]);                   /* waits for every member */
+
 /* ---- stateless kernels on caller-owned device memory (used by the parity tests) ---- */
 /* mm2metersKernel (+ bilateralFilterKernel when d_filtered != NULL) */
 int kfh_k_preprocess(float *d_raw, float *d_filtered, int ow, int oh, const uint16_t *d_in, int iw, int ih,

@@ -12,6 +12,7 @@
 #include <mutex>
 #include <new>
 #include <string>
+#include <vector>
 
 using namespace kfh;
 
@@ -706,19 +707,26 @@ int kfh_raycast(kfh_context *c) {
     return KFH_OK;
 }
 
-int kfh_raycast_slab(kfh_context *c) {
-    KFH_REQUIRE(c != nullptr, "context is NULL");
-    DeviceScope on_device(c->device);
+// The march of this context's slab into `segments` (a packed map of the compute size): the context's own packed map
+// for kfh_raycast_slab, a map of its own for the members of a group (whose peers read it while the context already
+// composites into its packed map).
+static int raycast_slab_to(kfh_context *c, float4 *segments) {
     if (int rc = flush_tail(c)) return rc;
     if (c->frame > 2) {
         if (int rc = prepare_ray_list(c)) return rc;
         c->model_maps_stale = true;
-        KFH_HIP(launch_raycast(nullptr, nullptr, nullptr, c->d_ref_tn, c->w, c->h, c->d_volume,
+        KFH_HIP(launch_raycast(nullptr, nullptr, nullptr, segments, c->w, c->h, c->d_volume,
                                c->cfg.vol_res, c->cfg.vol_dim, c->cfg.slab_z0, c->cfg.slab_z1, &c->d_ctrl->view, NEAR_PLANE,
                                FAR_PLANE, raycast_step(c->cfg), 0.75f * c->cfg.mu, c->d_ray_tasks,
                                &c->d_ctrl->ray_task_count, c->d_bricks, c->stream));
     }
     return KFH_OK;
+}
+
+int kfh_raycast_slab(kfh_context *c) {
+    KFH_REQUIRE(c != nullptr, "context is NULL");
+    DeviceScope on_device(c->device);
+    return raycast_slab_to(c, c->d_ref_tn);
 }
 
 int kfh_composite_slabs(kfh_context *c, const void *d_tn_parts, int n_parts) {
@@ -1230,6 +1238,205 @@ int kfh_k_integrate(void *d_volume, const int32_t res[3], const float dim[3], in
     (void)hipFree(scratch);
     KFH_HIP(e);
     return KFH_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// A group: ONE sequence whose volume is split into z-slabs over several contexts (one per listed device; a device
+// may be listed more than once), all driven from the calling thread.  This is the z-slab path for callers that are
+// a single process with a single thread of control - the SLAMBench harness loads a plugin into one process and
+// calls it frame by frame (framework/shared/src/SLAMBenchConfiguration.cpp:230-342) - where one process per GPU
+// and a collective library are not to be had.  Per frame every member preprocesses the frame, tracks on its own
+// copy of the model map (identical inputs: identical poses), integrates its slab and marches its slab's ray
+// segments into a map of its own; then every member composites the nearest hit per pixel straight out of all
+// members' segment maps (its own memory and its peers', read over the links: no copy, no collective).  Ordering
+// between the devices is by events: a member composites when all marches of the frame are done, and marches the
+// next frame's segments when all composites of this frame are done.
+// ------------------------------------------------------------------------------------------------------
+struct kfh_group {
+    std::vector<kfh_context *> member;
+    std::vector<float4 *> segments;          // per member: the packed map its slab march writes (on its device)
+    std::vector<hipEvent_t> marched, composited;
+    bool exchanged = false;                  // a composite has been queued since the group was created or reset
+};
+
+namespace {
+// planes [z0, z1) of slab `index` out of `count`: contiguous, nearly equal, the first res % count one plane larger
+void slab_range(int res, int count, int index, int *z0, int *z1) {
+    const int base = res / count, extra = res % count;
+    *z0 = index * base + (index < extra ? index : extra);
+    *z1 = *z0 + base + (index < extra ? 1 : 0);
+}
+
+void group_free(kfh_group *g) {
+    for (size_t i = 0; i < g->member.size(); ++i) {
+        kfh_context *c = g->member[i];
+        if (!c) continue;
+        DeviceScope on_device(c->device);
+        (void)hipStreamSynchronize(c->stream);
+        if (i < g->segments.size() && g->segments[i]) (void)hipFree(g->segments[i]);
+        if (i < g->marched.size() && g->marched[i]) (void)hipEventDestroy(g->marched[i]);
+        if (i < g->composited.size() && g->composited[i]) (void)hipEventDestroy(g->composited[i]);
+    }
+    for (kfh_context *c : g->member)
+        if (c) (void)kfh_destroy(c);
+    delete g;
+}
+}  // namespace
+
+int kfh_group_create(const kfh_config *cfg, const int *devices, int n, kfh_group **out) {
+    KFH_REQUIRE(out != nullptr, "out is NULL");
+    *out = nullptr;
+    KFH_REQUIRE(cfg != nullptr && devices != nullptr, "NULL argument");
+    KFH_REQUIRE(n >= 1 && n <= KFH_GROUP_MAX, "a group has 1 to %d members (got %d)", KFH_GROUP_MAX, n);
+    KFH_REQUIRE(cfg->vol_res[2] >= n, "more members (%d) than z planes (%d)", n, cfg->vol_res[2]);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        return fail(KFH_ERR_NO_DEVICE, "no HIP device is visible to this process");
+    for (int i = 0; i < n; ++i)
+        KFH_REQUIRE(devices[i] >= 0 && devices[i] < ndev, "device %d of member %d is not one of the %d visible devices",
+                    devices[i], i, ndev);
+    int caller_device = 0;
+    KFH_HIP(hipGetDevice(&caller_device));
+    kfh_group *g = new (std::nothrow) kfh_group();
+    if (!g) return fail(KFH_ERR_STATE, "out of host memory");
+    g->member.assign(n, nullptr);
+    g->segments.assign(n, nullptr);
+    g->marched.assign(n, nullptr);
+    g->composited.assign(n, nullptr);
+    int rc = KFH_OK;
+    for (int i = 0; i < n && rc == KFH_OK; ++i) {
+        // every member reads every other member's segment map: the devices must see each other's memory
+        for (int j = 0; j < n && rc == KFH_OK; ++j) {
+            if (devices[j] == devices[i]) continue;
+            int can = 0;
+            if (hipDeviceCanAccessPeer(&can, devices[i], devices[j]) != hipSuccess || !can)
+                rc = fail(KFH_ERR_STATE, "device %d cannot read the memory of device %d (no peer access)", devices[i], devices[j]);
+        }
+    }
+    for (int i = 0; i < n && rc == KFH_OK; ++i) {
+        if (hipSetDevice(devices[i]) != hipSuccess) { rc = fail(KFH_ERR_HIP, "hipSetDevice(%d) failed", devices[i]); break; }
+        for (int j = 0; j < n; ++j) {
+            if (devices[j] == devices[i]) continue;
+            const hipError_t e = hipDeviceEnablePeerAccess(devices[j], 0);
+            if (e == hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();
+            else if (e != hipSuccess) { rc = fail(KFH_ERR_HIP, "hipDeviceEnablePeerAccess(%d) on device %d: %s", devices[j], devices[i], hipGetErrorString(e)); break; }
+        }
+        if (rc != KFH_OK) break;
+        kfh_config member_cfg = *cfg;
+        if (n > 1) slab_range(cfg->vol_res[2], n, i, &member_cfg.slab_z0, &member_cfg.slab_z1);
+        rc = kfh_create(&member_cfg, &g->member[i]);
+        if (rc != KFH_OK) break;
+        kfh_context *c = g->member[i];
+        hipError_t e = dev_alloc(&g->segments[i], (size_t)c->w * c->h);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&g->marched[i], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&g->composited[i], hipEventDisableTiming);
+        if (e != hipSuccess) rc = fail(KFH_ERR_HIP, "group member %d: %s", i, hipGetErrorString(e));
+    }
+    (void)hipSetDevice(caller_device);
+    if (rc != KFH_OK) {
+        const std::string text = kfh_last_error();        // the clean-up below must not replace the reason
+        group_free(g);
+        return fail(rc, "%s", text.c_str());
+    }
+    *out = g;
+    return KFH_OK;
+}
+
+int kfh_group_destroy(kfh_group *g) {
+    if (!g) return KFH_OK;
+    group_free(g);
+    return KFH_OK;
+}
+
+int kfh_group_size(kfh_group *g, int *n) {
+    KFH_REQUIRE(g != nullptr && n != nullptr, "NULL argument");
+    *n = (int)g->member.size();
+    return KFH_OK;
+}
+
+int kfh_group_member(kfh_group *g, int index, kfh_context **ctx) {
+    KFH_REQUIRE(g != nullptr && ctx != nullptr, "NULL argument");
+    KFH_REQUIRE(index >= 0 && index < (int)g->member.size(), "member %d of %zu", index, g->member.size());
+    *ctx = g->member[index];
+    return KFH_OK;
+}
+
+int kfh_group_reset(kfh_group *g) {
+    KFH_REQUIRE(g != nullptr, "group is NULL");
+    for (kfh_context *c : g->member) {
+        if (int rc = kfh_sync(c)) return rc;       // no member may still read a segment map
+    }
+    for (kfh_context *c : g->member)
+        if (int rc = kfh_reset(c)) return rc;
+    g->exchanged = false;
+    return KFH_OK;
+}
+
+int kfh_group_upload_depth(kfh_group *g, const uint16_t *h_depth) {
+    KFH_REQUIRE(g != nullptr && h_depth != nullptr, "NULL argument");
+    for (kfh_context *c : g->member)
+        if (int rc = kfh_upload_depth(c, h_depth)) return rc;
+    return KFH_OK;
+}
+
+int kfh_group_set_depth_device(kfh_group *g, const uint16_t *const *d_depth_per_member) {
+    KFH_REQUIRE(g != nullptr && d_depth_per_member != nullptr, "NULL argument");
+    for (size_t i = 0; i < g->member.size(); ++i)
+        if (int rc = kfh_set_depth_device(g->member[i], d_depth_per_member[i])) return rc;
+    return KFH_OK;
+}
+
+int kfh_group_process_frame(kfh_group *g) {
+    KFH_REQUIRE(g != nullptr, "group is NULL");
+    const int n = (int)g->member.size();
+    if (n == 1) return kfh_process_frame(g->member[0]);
+    const bool raycasts = g->member[0]->frame > 2;
+    for (int i = 0; i < n; ++i) {
+        kfh_context *c = g->member[i];
+        DeviceScope on_device(c->device);
+        if (int rc = kfh_preprocess(c)) return rc;
+        if (int rc = kfh_track(c)) return rc;
+        if (int rc = kfh_integrate(c)) return rc;
+        if (raycasts) {
+            // the march overwrites the map the peers composited from in the frame before
+            if (g->exchanged)
+                for (int j = 0; j < n; ++j)
+                    if (j != i) KFH_HIP(hipStreamWaitEvent(c->stream, g->composited[j], 0));
+            if (int rc = raycast_slab_to(c, g->segments[i])) return rc;
+            KFH_HIP(hipEventRecord(g->marched[i], c->stream));
+        }
+    }
+    if (raycasts) {
+        for (int i = 0; i < n; ++i) {
+            kfh_context *c = g->member[i];
+            DeviceScope on_device(c->device);
+            for (int j = 0; j < n; ++j)
+                if (j != i) KFH_HIP(hipStreamWaitEvent(c->stream, g->marched[j], 0));
+            c->model_maps_stale = true;
+            KFH_HIP(launch_composite_parts(c->d_ref_tn, g->segments.data(), n, c->w * c->h, c->stream));
+            KFH_HIP(hipEventRecord(g->composited[i], c->stream));
+        }
+        g->exchanged = true;
+    }
+    for (kfh_context *c : g->member)
+        if (int rc = kfh_end_frame(c)) return rc;
+    return KFH_OK;
+}
+
+int kfh_group_sync(kfh_group *g) {
+    KFH_REQUIRE(g != nullptr, "group is NULL");
+    for (kfh_context *c : g->member)
+        if (int rc = kfh_sync(c)) return rc;
+    return KFH_OK;
+}
+
+int kfh_group_get_pose(kfh_group *g, float pose[16]) {
+    KFH_REQUIRE(g != nullptr && pose != nullptr, "NULL argument");
+    // every member holds the same pose (same inputs, same kernels); the others are waited for as well, so that the
+    // frame is over on every device when this returns
+    for (size_t i = 1; i < g->member.size(); ++i)
+        if (int rc = kfh_sync(g->member[i])) return rc;
+    return kfh_get_pose(g->member[0], pose);
 }
 
 // ------------------------------------------------------------------------------------------------------

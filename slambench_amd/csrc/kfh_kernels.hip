@@ -3133,6 +3133,33 @@ hipError_t launch_composite(float4 *ref_tn, const float4 *tn_parts, int n, int n
     return hipGetLastError();
 }
 
+// The same selection with every slab's candidates read where they lie: part[i] is the packed segment map of slab i,
+// in this device's memory or in a peer's (read over the link, 16 bytes per pixel and slab; nothing is copied first).
+// Candidates are taken in the order of the array, like the rows of the gathered array above: the same winners.
+struct CompositeParts { const float4 *part[KFH_GROUP_MAX]; };
+__global__ __launch_bounds__(256) void k_composite_parts(float4 *__restrict__ ref_tn, CompositeParts parts, int n, int npix) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= npix) return;
+    float4 cand[KFH_GROUP_MAX];
+#pragma unroll
+    for (int i = 0; i < KFH_GROUP_MAX; ++i)                  // all requests leave before the first is looked at
+        cand[i] = i < n ? parts.part[i][p] : make_float4(0.f, KFH_INVALID, 0.f, 0.f);
+    float4 best = make_float4(0.f, KFH_INVALID, 0.f, 0.f);
+    bool have = false;
+#pragma unroll
+    for (int i = 0; i < KFH_GROUP_MAX; ++i)
+        if (i < n && cand[i].x > 0.f && (!have || cand[i].x < best.x)) { best = cand[i]; have = true; }
+    ref_tn[p] = best;
+}
+
+hipError_t launch_composite_parts(float4 *ref_tn, const float4 *const *parts, int n, int npix, hipStream_t s) {
+    if (n < 1 || n > KFH_GROUP_MAX) return hipErrorInvalidValue;
+    CompositeParts cp;
+    for (int i = 0; i < KFH_GROUP_MAX; ++i) cp.part[i] = i < n ? parts[i] : nullptr;
+    hipLaunchKernelGGL(k_composite_parts, dim3((npix + 255) / 256), dim3(256), 0, s, ref_tn, cp, n, npix);
+    return hipGetLastError();
+}
+
 // Vertex, normal and hit-distance maps of the last raycast rebuilt from the packed map {t, normal}: the raycast
 // stored vertex = origin + direction * t with direction = rotate(view, (x, y, 1)); the same expressions on the same
 // matrix give the same bits, so a caller sees exactly what the raycast would have written.

@@ -24,18 +24,23 @@ def _device_pointer(obj):
 
 
 class KFusion:
-    def __init__(self, cfg: KFusionConfig):
+    def __init__(self, cfg: KFusionConfig, _borrowed_ctx=None):
         self.cfg = cfg
         self._L = native.lib()
-        self._ctx = C.c_void_p()
-        ccfg = cfg.to_c()
-        native.check(self._L.kfh_create(C.byref(ccfg), C.byref(self._ctx)))
+        self._owned = _borrowed_ctx is None
+        if self._owned:
+            self._ctx = C.c_void_p()
+            ccfg = cfg.to_c()
+            native.check(self._L.kfh_create(C.byref(ccfg), C.byref(self._ctx)))
+        else:                           # a member of a group: the group destroys it
+            self._ctx = _borrowed_ctx
         self.width, self.height = cfg.compute_size
 
     # ------------------------------------------------------------------ lifecycle
     def close(self):
         if getattr(self, "_ctx", None) and self._ctx.value:
-            self._L.kfh_destroy(self._ctx)
+            if self._owned:
+                self._L.kfh_destroy(self._ctx)
             self._ctx = C.c_void_p()
 
     def __del__(self):
@@ -190,3 +195,62 @@ class KFusion:
         else:
             native.check(self._L.kfh_phase_ms_frame(self._ctx, int(frame), ms.ctypes.data_as(C.c_void_p)))
         return ms
+
+
+class GroupKFusion:
+    """kfh_group of include/kfusion_hip.h: ONE sequence whose volume is split into z-slabs over several contexts of
+    this process (one per entry of `devices`; an index may repeat), driven from the calling thread.  `members` are
+    KFusion views of the contexts (status records, downloads); stepping a member on its own breaks the group."""
+
+    def __init__(self, cfg: KFusionConfig, devices):
+        from .sharded import slab_bounds
+        self.cfg = cfg
+        self._L = native.lib()
+        self._g = C.c_void_p()
+        devices = [int(d) for d in devices]
+        n = len(devices)
+        ccfg = cfg.to_c()
+        arr = (C.c_int * n)(*devices)
+        native.check(self._L.kfh_group_create(C.byref(ccfg), arr, n, C.byref(self._g)))
+        self.members = []
+        for i in range(n):
+            ctx = C.c_void_p()
+            native.check(self._L.kfh_group_member(self._g, i, C.byref(ctx)))
+            slab = slab_bounds(cfg.volume_resolution[2], n, i) if n > 1 else (0, 0)
+            self.members.append(KFusion(KFusionConfig(**{**cfg.__dict__, "slab": slab}), _borrowed_ctx=ctx))
+
+    def close(self):
+        if getattr(self, "_g", None) and self._g.value:
+            for m in self.members:
+                m.close()
+            self._L.kfh_group_destroy(self._g)
+            self._g = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def reset(self):
+        native.check(self._L.kfh_group_reset(self._g))
+
+    def process_frame(self, depth=None):
+        """depth: a host uint16 frame (uploaded to every member), or one device pointer per member."""
+        if depth is not None:
+            if isinstance(depth, np.ndarray):
+                d = np.ascontiguousarray(depth)
+                native.check(self._L.kfh_group_upload_depth(self._g, d.ctypes.data_as(C.c_void_p)))
+            else:
+                ptrs = (C.c_void_p * len(self.members))(*[_device_pointer(p) for p in depth])
+                native.check(self._L.kfh_group_set_depth_device(self._g, ptrs))
+        native.check(self._L.kfh_group_process_frame(self._g))
+
+    def sync(self):
+        native.check(self._L.kfh_group_sync(self._g))
+
+    @property
+    def pose(self):
+        out = np.empty(16, np.float32)
+        native.check(self._L.kfh_group_get_pose(self._g, out.ctypes.data_as(C.c_void_p)))
+        return out.reshape(4, 4)

@@ -27,6 +27,9 @@ EXPORTED_SYMBOLS = (
     "kfh_get_pose", "kfh_set_pose", "kfh_get_status", "kfh_frame_index", "kfh_integrate_totals", "kfh_compute_size",
     "kfh_download", "kfh_device_ptr", "kfh_stream", "kfh_set_timing", "kfh_phase_ms", "kfh_phase_ms_frame",
     "kfh_raycast_slab", "kfh_composite_slabs", "kfh_composite_tile", "kfh_track_rows",
+    "kfh_group_create", "kfh_group_destroy", "kfh_group_reset", "kfh_group_size", "kfh_group_member",
+    "kfh_group_upload_depth", "kfh_group_set_depth_device", "kfh_group_process_frame", "kfh_group_sync",
+    "kfh_group_get_pose",
     "kfh_render", "kfh_render_device", "kfh_enable_track_render",
     "kfh_k_render_depth", "kfh_k_render_track", "kfh_k_render_volume",
     "kfh_k_preprocess", "kfh_k_bilateral", "kfh_k_half_sample", "kfh_k_vertex_normal",
@@ -86,6 +89,11 @@ def lib():
         "kfh_raycast_slab": [vp], "kfh_composite_slabs": [vp, vp, i32],
         "kfh_composite_tile": [vp, vp, i32, i32, i32, vp],
         "kfh_track_rows": [vp, i32, i32, ALLREDUCE_FN, vp],
+        "kfh_group_create": [C.POINTER(KfhConfig), C.POINTER(C.c_int), i32, C.POINTER(vp)],
+        "kfh_group_destroy": [vp], "kfh_group_reset": [vp], "kfh_group_size": [vp, C.POINTER(C.c_int)],
+        "kfh_group_member": [vp, i32, C.POINTER(vp)],
+        "kfh_group_upload_depth": [vp, vp], "kfh_group_set_depth_device": [vp, C.POINTER(vp)],
+        "kfh_group_process_frame": [vp], "kfh_group_sync": [vp], "kfh_group_get_pose": [vp, vp],
         "kfh_k_preprocess": [vp, vp, i32, i32, vp, i32, i32, f32, vp],
         "kfh_k_bilateral": [vp, vp, i32, i32, vp],
         "kfh_k_half_sample": [vp, vp, i32, i32, f32, vp],

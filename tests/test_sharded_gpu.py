@@ -134,3 +134,62 @@ def test_slab_raycast_with_brick_marks_equals_the_one_without(torch_cuda, monkey
         assert np.array_equal(a, b)
     assert all(np.array_equal(a, b) for a, b in zip(traj, traj_plain))
     assert (maps[-1][..., 0] > 0).any(axis=0).mean() > 0.5          # the composite hits most pixels
+
+
+@pytest.mark.parametrize("members", [2, 3])
+def test_group_inside_one_process_gives_the_bits_of_the_gather_exchange(torch_cuda, members):
+    """kfh_group (one thread, the members' composites reading each other's segment maps in place, ordered by events)
+    against the construction above: every slab marched by kfh_raycast_slab, the segment maps stacked and every context
+    compositing with kfh_composite_slabs - what the one-process-per-rank path does with an all-gather in between."""
+    from slambench_amd.kfusion import GroupKFusion
+    torch = torch_cuda
+    V, frames = 96, 14                    # 96 planes: the slab boundaries of three members are off the brick grid
+    base = dict(compute_size_ratio=2, volume_resolution=(V, V, V))
+    depth, _, _ = synth.make_sequence(frames, seed=1)
+    L = native.lib()
+    slabs = [KFusion(KFusionConfig(**base, slab=slab_bounds(V, members, r))) for r in range(members)]
+    for i in range(frames):
+        for kf in slabs:
+            kf.set_depth(depth[i])
+            kf.preprocessing()
+            kf.tracking()
+            kf.integration()
+            native.check(L.kfh_raycast_slab(kf._ctx))
+        if i > 2:
+            tn = torch.from_numpy(np.stack([kf.download(native.BUF_MODEL_TN) for kf in slabs])).cuda()
+            for kf in slabs:
+                native.check(L.kfh_composite_slabs(kf._ctx, C.c_void_p(tn.data_ptr()), members))
+        for kf in slabs:
+            kf.end_frame()
+    group = GroupKFusion(KFusionConfig(**base), [0] * members)
+    for i in range(frames):
+        group.process_frame(depth[i])
+    pose = group.pose
+    assert np.array_equal(pose, slabs[0].pose)
+    tracked = [slabs[0].status(f)["tracked"] for f in range(frames)]
+    assert all(tracked[4:]), "the sequence must track once the model exists"
+    for r in range(members):
+        m = group.members[r]
+        assert np.array_equal(m.trajectory(), slabs[r].trajectory())
+        assert [m.status(f)["tracked"] for f in range(frames)] == tracked
+        assert np.array_equal(m.download(native.BUF_MODEL_TN), slabs[r].download(native.BUF_MODEL_TN))
+        assert np.array_equal(m.download(native.BUF_VOLUME), slabs[r].download(native.BUF_VOLUME))
+    # a reset group runs the same sequence to the same bits
+    group.reset()
+    for i in range(frames):
+        group.process_frame(depth[i])
+    assert np.array_equal(group.pose, pose)
+    group.close()
+    for kf in slabs:
+        kf.close()
+
+
+def test_group_rejects_what_it_cannot_run(torch_cuda):
+    from slambench_amd.kfusion import GroupKFusion
+    cfg = KFusionConfig(compute_size_ratio=4, volume_resolution=(32, 32, 32))
+    with pytest.raises(native.KfhError):
+        GroupKFusion(cfg, [0] * 17)           # at most 16 members
+    with pytest.raises(native.KfhError):
+        GroupKFusion(cfg, [0, 99])            # no such device
+    with pytest.raises(native.KfhError):
+        GroupKFusion(cfg, [])
