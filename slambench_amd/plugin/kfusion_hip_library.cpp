@@ -41,15 +41,18 @@ const sb_float3 default_volume_size = {8.f, 8.f, 8.f};
 const sb_float3 default_volume_direction = {4.f, 4.f, 4.f};
 const sb_uint3 default_volume_resolution = {256, 256, 256};
 const int default_pyramid[3] = {10, 5, 4};
+const int default_devices = 1;
 
 int compute_size_ratio, integration_rate, tracking_rate, rendering_rate;
 float icp_threshold, mu;
 sb_float3 volume_size, volume_direction;
 sb_uint3 volume_resolution;
 int pyramid_level1, pyramid_level2, pyramid_level3;
+int devices;           // not a parameter of the kfusion use-case: GPUs the volume is split over (z-slabs, kfh_group)
 
 // ---- run state (sb_clean_slam_system takes no argument, so the state is file-scope like upstream's) ----
-kfh_context *ctx = nullptr;
+kfh_context *ctx = nullptr;       // the context; with --devices N > 1 the first member of `group`
+kfh_group *group = nullptr;
 slambench::io::DepthSensor *depth_sensor = nullptr;
 slambench::outputs::Output *pose_output = nullptr;
 slambench::outputs::Output *pointcloud_output = nullptr;
@@ -87,6 +90,10 @@ bool sb_new_slam_configuration(SLAMBenchLibraryHelper *slam_settings) {
     slam_settings->addParameter(TypedParameter<int>("y1", "pyramid-level1", "pyramid-level1", &pyramid_level1, &default_pyramid[0]));
     slam_settings->addParameter(TypedParameter<int>("y2", "pyramid-level2", "pyramid-level2", &pyramid_level2, &default_pyramid[1]));
     slam_settings->addParameter(TypedParameter<int>("y3", "pyramid-level3", "pyramid-level3", &pyramid_level3, &default_pyramid[2]));
+    // One harness process drives one plugin (reference framework/shared/src/SLAMBenchConfiguration.cpp:230-342), so a
+    // volume too large or too slow for one GPU is split inside the plugin: N z-slabs on the first N visible devices
+    // (more slabs than devices wrap around).
+    slam_settings->addParameter(TypedParameter<int>("n", "devices", "GPUs the volume is split over (z-slabs)", &devices, &default_devices));
     return true;
 }
 
@@ -129,7 +136,16 @@ bool sb_init_slam_system(SLAMBenchLibraryHelper *slam_settings) {
     cfg.integrate_filtered = 0;
     cfg.slab_z0 = 0;
     cfg.slab_z1 = cfg.vol_res[2];
-    if (!report("kfh_create", kfh_create(&cfg, &ctx))) return false;
+    if (devices > 1) {
+        int visible = 0;
+        if (!report("kfh_device_count", kfh_device_count(&visible)) || visible < 1) return false;
+        std::vector<int> list((size_t)devices);
+        for (int i = 0; i < devices; ++i) list[(size_t)i] = i % visible;
+        if (!report("kfh_group_create", kfh_group_create(&cfg, list.data(), devices, &group))) return false;
+        if (!report("kfh_group_member", kfh_group_member(group, 0, &ctx))) return false;
+    } else if (!report("kfh_create", kfh_create(&cfg, &ctx))) {
+        return false;
+    }
 
     frame_bytes = (size_t)cfg.input_width * cfg.input_height * sizeof(uint16_t);
     depth_ready = false;
@@ -169,7 +185,9 @@ bool sb_update_frame(SLAMBenchLibraryHelper *, slambench::io::SLAMFrame *s) {
     // The harness reuses one buffer for all frames, so the bytes are copied out before FreeData(): straight into
     // the core's pinned staging slot, from where the transfer to the device is queued at once and runs while the
     // harness is still between sb_update_frame and sb_process_once.
-    const bool ok = report("kfh_upload_depth", kfh_upload_depth(ctx, static_cast<const uint16_t *>(s->GetData())));
+    const uint16_t *pixels = static_cast<const uint16_t *>(s->GetData());
+    const bool ok = group ? report("kfh_group_upload_depth", kfh_group_upload_depth(group, pixels))
+                          : report("kfh_upload_depth", kfh_upload_depth(ctx, pixels));
     s->FreeData();
     depth_ready = ok;
     return ok;
@@ -181,6 +199,16 @@ bool sb_process_once(SLAMBenchLibraryHelper *slam_settings) {
     for (int i = 0; i < 5; ++i) phase[i] = mm.GetPhase(phase_names[i]);
     bool ok = true;
 
+    if (group) {
+        // the stages of all members are queued by one call (it also ends the members' frame); the phases are still
+        // bracketed, as the harness reads every declared phase in every frame
+        phase[0]->Begin();
+        ok = ok && report("kfh_group_process_frame", kfh_group_process_frame(group));
+        phase[0]->End();
+        phase[1]->Begin(); phase[1]->End();
+        phase[2]->Begin(); phase[2]->End();
+        phase[3]->Begin();
+    } else {
     phase[0]->Begin();
     ok = ok && report("kfh_preprocess", kfh_preprocess(ctx));
     phase[0]->End();
@@ -192,12 +220,14 @@ bool sb_process_once(SLAMBenchLibraryHelper *slam_settings) {
     phase[2]->End();
     phase[3]->Begin();
     ok = ok && report("kfh_raycast", kfh_raycast(ctx));
+    }
     // The phases above only queue work; the frame's device time is accounted here, once, so that
     // Duration_Frame is honest (the reference's GPU builds show near-zero phases for the same reason:
     // host timers without a device synchronisation, framework/shared/src/metrics/DurationMetric.cpp:65-71).
     // Waiting for the pose waits for everything queued so far; the second pass of the raycast, which only the
     // next frame's tracking needs, stays postponed and shares the next frame's preprocessing launch.
-    ok = ok && report("kfh_get_pose", kfh_get_pose(ctx, frame_pose));
+    ok = ok && (group ? report("kfh_group_get_pose", kfh_group_get_pose(group, frame_pose))
+                      : report("kfh_get_pose", kfh_get_pose(ctx, frame_pose)));
     phase[3]->End();
     // Render: the depth and tracking pictures every frame, the volume picture every rendering-rate frames, as
     // the Duration_Render column of the reference's logs shows (two levels, the high one on rows 1, 5, 9, ...).
@@ -206,7 +236,8 @@ bool sb_process_once(SLAMBenchLibraryHelper *slam_settings) {
     {
         const bool want_depth = render_always || depth_frame_output->IsActive();
         const bool want_track = render_always || track_frame_output->IsActive();
-        const bool want_volume = (render_always || render_frame_output->IsActive()) && rendering_rate > 0 &&
+        // (the volume picture needs the whole volume on one device: not drawn for a split volume)
+        const bool want_volume = !group && (render_always || render_frame_output->IsActive()) && rendering_rate > 0 &&
                                  (frame_counter % rendering_rate) == 0;
         if (want_depth) {
             ok = ok && report("kfh_render(depth)", kfh_render(ctx, KFH_RENDER_DEPTH, nullptr, depth_image.data(), depth_image.size()));
@@ -226,7 +257,7 @@ bool sb_process_once(SLAMBenchLibraryHelper *slam_settings) {
         }
     }
     phase[4]->End();
-    ok = ok && report("kfh_end_frame", kfh_end_frame(ctx));
+    if (!group) ok = ok && report("kfh_end_frame", kfh_end_frame(ctx));
     depth_ready = false;
     frame_counter++;
     return ok;
@@ -269,8 +300,9 @@ bool sb_update_outputs(SLAMBenchLibraryHelper *lib, const slambench::TimeStamp *
 }
 
 bool sb_clean_slam_system() {
-    const bool ok = report("kfh_destroy", kfh_destroy(ctx));
+    const bool ok = group ? report("kfh_group_destroy", kfh_group_destroy(group)) : report("kfh_destroy", kfh_destroy(ctx));
     ctx = nullptr;
+    group = nullptr;
     depth_sensor = nullptr;
     return ok;
 }

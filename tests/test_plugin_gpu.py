@@ -218,3 +218,45 @@ def test_reference_written_files_and_reference_frame_counting(torch_cuda, tmp_pa
     r = harness.run_mini_harness(full, args + ["-s", "2"], frame_limit=3)
     assert r.returncode == 0, r.stderr
     np.testing.assert_allclose(harness.parse_log(r.stdout)[2][:, 1], ts[2:5], atol=1e-8)
+
+
+def test_devices_option_splits_the_volume_inside_the_plugin(torch_cuda, tmp_path):
+    """`--devices 2`: the plugin runs the sequence on a group of two z-slab contexts (both on GPU 0 here) and the
+    harness, a single process calling frame by frame, sees one library: its trajectory is the one of the in-process
+    two-slab construction of tests/test_sharded_gpu.py (kfh_raycast_slab + stacked maps + kfh_composite_slabs)."""
+    import ctypes as C
+    from slambench_amd import native
+    from slambench_amd.sharded import slab_bounds
+    n, V = 12, 128
+    intr = (481.2, 480.0, 319.5, 239.5)
+    depth, gt, ts = synth.make_sequence(n, seed=1, intrinsics=intr)
+    path = str(tmp_path / "stream.kfd")
+    harness.write_kfd(path, depth, ts, intr, 0.001)
+    r = harness.run_mini_harness(path, ["--compute-size-ratio", "2", "--volume-resolution", "%d,%d,%d" % (V, V, V),
+                                        "--devices", "2"])
+    assert r.returncode == 0, r.stderr
+    props, cols, rows = harness.parse_log(r.stdout)
+    assert props["devices"] == "2" and rows.shape[0] == n
+    w, h = 640, 480
+    intr_rt = tuple(float(np.float32(v / s) * np.float32(s)) for v, s in zip(intr, (w, h, w, h)))
+    base = dict(intrinsics=intr_rt, compute_size_ratio=2, volume_resolution=(V, V, V))
+    slabs = [KFusion(KFusionConfig(**base, slab=slab_bounds(V, 2, k))) for k in range(2)]
+    L = native.lib()
+    for i in range(n):
+        for kf in slabs:
+            kf.set_depth(depth[i])
+            kf.preprocessing()
+            kf.tracking()
+            kf.integration()
+            native.check(L.kfh_raycast_slab(kf._ctx))
+        if i > 2:
+            tn = torch_cuda.from_numpy(np.stack([kf.download(native.BUF_MODEL_TN) for kf in slabs])).cuda()
+            for kf in slabs:
+                native.check(L.kfh_composite_slabs(kf._ctx, C.c_void_p(tn.data_ptr()), 2))
+        for kf in slabs:
+            kf.end_frame()
+    traj = slabs[0].trajectory()
+    assert slabs[0].status(n - 1)["tracked"] and np.abs(traj[-1, :3, 3] - 4.0).max() > 1e-3
+    np.testing.assert_allclose(rows[:, 8:11], traj[:, :3, 3], rtol=0, atol=1e-6)     # the log prints 10 decimals
+    for kf in slabs:
+        kf.close()
