@@ -81,6 +81,9 @@ def parse_args():
     ap.add_argument("--no-zslab-leg", action="store_true", help="N>1, replicas: skip the additional z-slab leg")
     ap.add_argument("--pg-timeout", type=float, default=180.0,
                     help="seconds after which a collective that does not complete ends the run (non-zero exit)")
+    ap.add_argument("--track-stats-csv", default=os.path.join(ROOT, "profiles", "r3_kernel_stats.csv"),
+                    help="rocprofv3 --kernel-trace --stats table of this command (tools/profile_round.sh): source of "
+                         "the per-level launch durations behind roofline_track")
     ap.add_argument("--dense-traffic-json", default=os.path.join(ROOT, "profiles", "r2_dense_integrate.json"),
                     help="counter bytes of the dense integration leg (tools/make_profiles.py --dense)")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "integrate_traffic.json"),
@@ -215,6 +218,44 @@ def dense_integrate_leg(KFusion, KFusionConfig, intrinsics, V, torch, band=False
             "note": "frac from the median, frac_mean from the mean of the HIP-event durations (plan + work launch) of "
                     "the timed integrations",
             "workload": what + ", 8 B x V^3 per launch"}
+
+
+def track_roofline(stats_csv, compute_size, tracking_ms):
+    """Track + reduce (one k_icp_iteration launch per ICP iteration) against the HBM roofline, per pyramid level:
+    36 algorithmic bytes per pixel of the level (five 4-byte input depths the vertex and normal are rebuilt from, and
+    the 16-byte packed model map entry the pixel gathers) / the launch's average duration.  The durations are those of
+    a committed rocprofv3 kernel trace of this command (the pipeline has no per-launch events of its own);
+    tracking_ms is this run's HIP-event time of the whole tracking phase on sampled frames."""
+    import csv
+    import re
+    w, h = compute_size
+    # block shapes the library picks per level for a 640 x 480 compute size (one instantiation per level)
+    level_of_shape = {(7, 3): 0, (5, 1): 1, (3, 1): 2}
+    out = {"kernel": "k_icp_iteration (trackKernel + reduceKernel + the previous iteration's solve)", "bound": "hbm",
+           "peak": HBM_PEAK_GBS, "unit": "GB/s", "bytes_per_pixel": 36, "tracking_ms_per_frame_this_run": tracking_ms,
+           "levels": None, "source": None}
+    if (w, h) != (640, 480) or not os.path.exists(stats_csv):
+        return out
+    levels = {}
+    with open(stats_csv) as f:
+        for r in csv.DictReader(f):
+            m = re.search(r"k_icp_iteration<\w+, (\d+), (\d+)>", r["Name"])
+            if not m or (int(m.group(1)), int(m.group(2))) not in level_of_shape:
+                continue
+            lvl = level_of_shape[(int(m.group(1)), int(m.group(2)))]
+            pixels = (w >> lvl) * (h >> lvl)
+            avg_s = float(r["AverageNs"]) * 1e-9
+            gbs = 36.0 * pixels / avg_s / 1e9
+            levels["level%d" % lvl] = {"pixels": pixels, "launches": int(r["Calls"]), "avg_us": avg_s * 1e6,
+                                       "achieved": gbs, "frac": gbs / HBM_PEAK_GBS}
+    if levels:
+        out["levels"] = levels
+        out["achieved"] = levels.get("level0", {}).get("achieved")
+        out["frac"] = levels.get("level0", {}).get("frac")
+        out["source"] = ("profiles/%s: rocprofv3 --kernel-trace --stats of an earlier run of this command; the average "
+                         "includes the launches of a converged level, which return at once; not measured in this run"
+                         % os.path.basename(stats_csv))
+    return out
 
 
 def reduce_ranks(values, op, dist, torch, backend, world):
@@ -353,7 +394,7 @@ def main():
     n_unique = max(8, min(a.unique_frames, total))
     seed = 1 if zslab else 1 + rank          # sharded: every rank sees the same frames (broadcast input)
     depth, gt, ts = synth.make_sequence(n_unique, seed=seed, intrinsics=TUM_FR1_DEPTH_INTRINSICS, noise=True)
-    order = ping_pong(n_unique, total + 300)
+    order = ping_pong(n_unique, total + 340)
     d_depth = torch.from_numpy(depth.view(np.int16)).cuda()      # every frame resident in HBM
     frame_ptrs = [int(d_depth[i].data_ptr()) for i in range(n_unique)]
 
@@ -471,6 +512,21 @@ def main():
     est = np.stack([kf.status(f)["pose"] for f in range(n_fwd)]) if total <= 4096 else None
     ate_hip = ate(est, gt[:n_fwd], ts[:n_fwd], ts[:n_fwd])["rmse"] if est is not None else None
 
+    # the tracking phase by HIP events on a few more frames (all four phases are timed then, which costs the stream
+    # a few microseconds per event: after the timed region)
+    tracking_ms = None
+    after = total                       # next frame of the stream
+    if not zslab and not extra:
+        kf.set_timing(1)
+        t_frames = []
+        for i in range(32):
+            step(order[after])
+            after += 1
+            t_frames.append(kf.frame - 1)
+        kf.sync()
+        tracking_ms = float(np.mean([kf.phase_ms(f)[1] for f in t_frames[8:]]))
+        kf.set_timing(0)
+
     # frames handed over in host memory (after the records of the timed region have been read: it moves the
     # context's frame counter on)
     pcie_fps = None
@@ -479,7 +535,7 @@ def main():
         kf.sync()
         th = time.perf_counter()
         for i in range(n_host):
-            kf.process_frame(depth[order[total + i]])     # numpy frame: kfh_upload_depth per frame
+            kf.process_frame(depth[order[after + i]])     # numpy frame: kfh_upload_depth per frame
         kf.sync()
         pcie_fps = n_host / (time.perf_counter() - th)
 
@@ -548,6 +604,8 @@ def main():
                         "8 B x V^3 / that duration is integrate_gvox_per_s x 8, not a bandwidth",
             },
         }
+        if not zslab:
+            result["roofline_track"] = track_roofline(a.track_stats_csv, cfg.compute_size, tracking_ms)
         if not a.no_dense_leg and not zslab and world == 1:
             result["roofline_dense"] = dense_integrate_leg(KFusion, KFusionConfig, TUM_FR1_DEPTH_INTRINSICS, V, torch)
             result["roofline_dense_band"] = dense_integrate_leg(KFusion, KFusionConfig, TUM_FR1_DEPTH_INTRINSICS, V,

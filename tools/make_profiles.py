@@ -1,6 +1,7 @@
 """Condense rocprofv3 output directories (merged back under gpurun_out/) into the tracked files of profiles/.
 
 usage: make_profiles.py TAG FRAMES KERNEL_TRACE_DIR FETCH_PMC_DIR WRITE_PMC_DIR [VOLUME]
+       (FRAMES = 0: the frames are counted in the trace, one tracking-finish launch per frame)
 
 Writes profiles/TAG_kernel_stats.csv (rocprofv3's own per-kernel statistics, verbatim),
 profiles/TAG_kernel_summary.txt, profiles/TAG_pmc_per_kernel.json (mean counter value per launch and kernel)
@@ -26,16 +27,26 @@ def short(name):
     return name.split("(")[0].replace("void ", "").replace("kfh::", "")
 
 
+def frames_in_trace(rows):
+    """Frames a kernel trace holds: every frame ends its tracking with one k_icp_finish launch (or one k_track_skip
+    when tracking is not due), whatever else the traced program ran."""
+    return sum(int(r["Calls"]) for r in rows if short(r["Name"]) in ("k_icp_finish", "k_track_skip"))
+
+
 def kernel_summary(d, frames):
     f = glob.glob(d + "/**/*kernel_stats.csv", recursive=True)[0]
     rows = list(csv.DictReader(open(f)))
     tot = sum(int(r["TotalDurationNs"]) for r in rows)
+    if frames <= 0:
+        frames = max(1, frames_in_trace(rows))
     out = ["%-28s %7s %10s %10s %6s %9s %9s" % ("kernel", "calls", "total_ms", "avg_us", "%", "min_us", "max_us")]
     for r in rows:
         out.append("%-28s %7s %10.2f %10.1f %6.1f %9.1f %9.1f" % (
             short(r["Name"])[-28:], r["Calls"], int(r["TotalDurationNs"]) / 1e6, float(r["AverageNs"]) / 1e3,
             100 * int(r["TotalDurationNs"]) / tot, int(r["MinNs"]) / 1e3, int(r["MaxNs"]) / 1e3))
-    out.append("total kernel time %.2f ms; %.1f us per frame over %d frames" % (tot / 1e6, tot / frames / 1e3, frames))
+    upload = sum(int(r["TotalDurationNs"]) for r in rows if "upload" in short(r["Name"]))
+    out.append("total kernel time %.2f ms; %.1f us per frame over %d frames (%.1f us without the upload kernels of "
+               "the host-frame leg)" % (tot / 1e6, tot / frames / 1e3, frames, (tot - upload) / frames / 1e3))
     return f, "\n".join(out) + "\n"
 
 
@@ -55,7 +66,7 @@ def dense(tag, base, volume=512):
     """profiles/TAG_dense_*: kernel summary of tools/dense_leg.py under the profiler and the counter bytes of its
     k_integrate launches next to the 8 B x V^3 they must move."""
     prof = os.path.join(ROOT, "profiles")
-    stats_csv, text = kernel_summary(os.path.join(base, "dense_kt"), 16)
+    stats_csv, text = kernel_summary(os.path.join(base, "dense_kt"), 0)
     with open(os.path.join(prof, tag + "_dense_kernel_summary.txt"), "w") as f:
         f.write(text)
     pmc = {}

@@ -5,7 +5,7 @@
 # gpurun_out/prof_TAG/.
 # usage (on the GPU box, from the repository root): bash tools/profile_round.sh TAG
 # then, where gpurun_out/ has been merged back:
-#   python tools/make_profiles.py TAG 310 gpurun_out/prof_TAG/kt gpurun_out/prof_TAG/fetch gpurun_out/prof_TAG/write
+#   python tools/make_profiles.py TAG 0 gpurun_out/prof_TAG/kt gpurun_out/prof_TAG/fetch gpurun_out/prof_TAG/write
 #   python tools/make_profiles.py --dense TAG gpurun_out/prof_TAG
 set -e
 TAG=${1:-round}
