@@ -81,6 +81,10 @@ def parse_args():
     ap.add_argument("--no-zslab-leg", action="store_true", help="N>1, replicas: skip the additional z-slab leg")
     ap.add_argument("--pg-timeout", type=float, default=180.0,
                     help="seconds after which a collective that does not complete ends the run (non-zero exit)")
+    ap.add_argument("--dataset", default="auto",
+                    help="compare the plugin with the reference's published kfusion-cpp log on a dataset file "
+                         "(slambench_amd/refcheck.py): a file name the reference's logs know, 'auto' = every such "
+                         "file found under KFH_DATASET_DIR or datasets/, 'none' = skip.  Reported as dataset_check")
     ap.add_argument("--track-stats-csv", default=os.path.join(ROOT, "profiles", "r3_kernel_stats.csv"),
                     help="rocprofv3 --kernel-trace --stats table of this command (tools/profile_round.sh): source of "
                          "the per-level launch durations behind roofline_track")
@@ -604,6 +608,17 @@ def main():
                         "8 B x V^3 / that duration is integrate_gvox_per_s x 8, not a bandwidth",
             },
         }
+        if a.dataset != "none" and world == 1:
+            # real data, when somebody has put it on the machine: the only numeric pins the reference holds for this path
+            from slambench_amd import refcheck
+            names = sorted(refcheck.REFERENCE_HEADS) if a.dataset == "auto" else [a.dataset]
+            checks = []
+            for name in names:
+                try:
+                    checks.append(refcheck.check_dataset(name))
+                except Exception as exc:
+                    checks.append({"dataset": name, "status": "failed", "error": "%s: %s" % (type(exc).__name__, exc)})
+            result["dataset_check"] = checks
         if not zslab:
             result["roofline_track"] = track_roofline(a.track_stats_csv, cfg.compute_size, tracking_ms)
         if not a.no_dense_leg and not zslab and world == 1:

@@ -62,6 +62,8 @@ std::vector<uint8_t> depth_image, track_image, volume_image;   // RGBA of the co
 bool depth_image_fresh = false, track_image_fresh = false, volume_image_fresh = false;
 bool track_codes_on = false;
 bool render_always = false;    // KFH_RENDER_ALWAYS: render like the reference, whether or not anybody looks
+bool log_schedule = false;     // KFH_LOG_SCHEDULE: one line per frame on stderr with what the frame did (tracked,
+                               //   integrated, raycasted), for comparisons with the phase columns of a reference log
 int image_w = 0, image_h = 0;
 size_t frame_bytes = 0;
 float frame_pose[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};   // pose after the last sb_process_once
@@ -169,6 +171,7 @@ bool sb_init_slam_system(SLAMBenchLibraryHelper *slam_settings) {
     depth_image_fresh = track_image_fresh = volume_image_fresh = false;
     track_codes_on = false;
     render_always = std::getenv("KFH_RENDER_ALWAYS") != nullptr;
+    log_schedule = std::getenv("KFH_LOG_SCHEDULE") != nullptr;
     slambench::outputs::Output **frame_outputs[3] = {&depth_frame_output, &track_frame_output, &render_frame_output};
     const char *const frame_names[3] = {"Depth Frame", "Tracking Frame", "Rendered frame"};
     for (int i = 0; i < 3; ++i) {
@@ -258,6 +261,12 @@ bool sb_process_once(SLAMBenchLibraryHelper *slam_settings) {
     }
     phase[4]->End();
     if (!group) ok = ok && report("kfh_end_frame", kfh_end_frame(ctx));
+    if (log_schedule && ok) {
+        kfh_frame_status st;
+        ok = report("kfh_get_status", kfh_get_status(ctx, frame_counter, &st));
+        if (ok) std::fprintf(stderr, "kfusion-hip: schedule frame %d tracked %d integrated %d raycasted %d\n", frame_counter,
+                             st.tracked, st.integrated, st.raycasted);
+    }
     depth_ready = false;
     frame_counter++;
     return ok;
