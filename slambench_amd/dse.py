@@ -18,11 +18,16 @@ from . import harness
 
 
 def parse_dse(text):
-    """`--dse` output -> {long option: {"short-option":, "type":, "default":, "values": [...], "min":, "max":}}."""
-    params, cur = {}, None
+    """`--dse` output -> {long option: {"short-option":, "type":, "default":, "values": [...], "min":, "max":}}.  A
+    library loaded under an identifier prints its arguments as "<id>-<name>" (the "libs:" line gives the identifier):
+    the keys here are the plain names."""
+    params, cur, prefix = {}, None, ""
     for line in text.splitlines():
-        if line.startswith("argument:"):
-            cur = params.setdefault(line[len("argument:"):], {})
+        if line.startswith("libs:"):
+            prefix = line[len("libs:"):].strip() + "-"
+        elif line.startswith("argument:"):
+            name = line[len("argument:"):]
+            cur = params.setdefault(name[len(prefix):] if prefix != "-" and name.startswith(prefix) else name, {})
         elif cur is not None and ":" in line:
             k, v = line.split(":", 1)
             if k == "values":
@@ -100,11 +105,12 @@ def run_sweep(points, make_cmd, gpus, timeout=3600, env=None, summarise_fn=None)
 
 def mini_harness_cmd(input_path, fixed_args=(), frame_limit=0):
     def make(point):
-        cmd = [harness.MINI_HARNESS_PATH, "-i", input_path, "-load", harness.PLUGIN_PATH]
+        # loaded under an identifier: the harness's own "-s" otherwise hides the plugin's options from volume-size on
+        cmd = [harness.MINI_HARNESS_PATH, "-i", input_path, "-load", harness.PLUGIN_PATH + "=" + harness.LIBRARY_ID]
         if frame_limit:
             cmd += ["-fl", str(frame_limit)]
-        cmd += list(fixed_args)
+        args = list(fixed_args)
         for k, v in point.items():
-            cmd += ["--" + k, str(v)]
-        return cmd
+            args += ["--" + k, str(v)]
+        return cmd + harness.plugin_options_with_id(args)
     return make

@@ -50,8 +50,31 @@ def read_kfd(path):
     return depth, ts, (intr[0] * w, intr[1] * h, intr[2] * w, intr[3] * h), scale
 
 
-def parse_log(text):
-    """Returns (properties dict, column names, rows as float array)."""
+LIBRARY_ID = "kf"       # identifier the helpers below load the plugin under: -load file.so=kf
+# options of the harness itself (the mini-harness knows these; everything else on its command line is the plugin's)
+HARNESS_OPTIONS = ("-i", "--input", "-load", "--load-library", "-o", "--log-file", "-fl", "--frame-limit", "-s",
+                   "--start-frame", "--reference-frame-limit", "--dump-frames", "-dse", "--dse")
+
+
+def plugin_options_with_id(args, library_id=LIBRARY_ID):
+    """The plugin's options as they are spelt for a library loaded as file.so=<id>: -x becomes -<id>-x and --name becomes
+    --<id>-name (reference framework/shared/include/Parameters.h:152-153); harness options and values stay."""
+    out = []
+    for a in args:
+        a = str(a)
+        is_option = a.startswith("-") and len(a) > 1 and not (a[1].isdigit() or a[1] == ".")
+        if not library_id or not is_option or a in HARNESS_OPTIONS:
+            out.append(a)
+        elif a.startswith("--"):
+            out.append("--%s-%s" % (library_id, a[2:]))
+        else:
+            out.append("-%s-%s" % (library_id, a[1:]))
+    return out
+
+
+def parse_log(text, library_id=LIBRARY_ID):
+    """Returns (properties dict, column names, rows as float array).  Property names lose the "<library_id>-" in front
+    of a library's parameters, so that a run loaded with an identifier reads like one without."""
     props, cols, rows = {}, [], []
     section = None
     for line in text.splitlines():
@@ -61,6 +84,8 @@ def parse_log(text):
             section = "stats"
         elif section == "props" and ": " in line:
             k, v = line.split(": ", 1)
+            if library_id and k.startswith(library_id + "-"):
+                k = k[len(library_id) + 1:]
             props[k] = v
         elif section == "stats" and line.startswith("Frame Number"):
             cols = line.split("\t")
@@ -69,11 +94,16 @@ def parse_log(text):
     return props, cols, np.asarray(rows)
 
 
-def run_mini_harness(kfd_path, plugin_args=(), frame_limit=0, library=PLUGIN_PATH, timeout=300):
-    cmd = [MINI_HARNESS_PATH, "-i", kfd_path, "-load", library]
+def run_mini_harness(kfd_path, plugin_args=(), frame_limit=0, library=PLUGIN_PATH, timeout=300, library_id=LIBRARY_ID):
+    """Run the mini-harness on a stream.  The plugin is loaded under an identifier (file.so=kf) and plugin_args, given
+    with the plugin's plain option names, are rewritten to carry it: without an identifier the reference's option
+    table drops every plugin option from "-s" (volume-size) on, because the harness owns a "-s" itself
+    (reference framework/shared/src/ParameterManager.cpp:115-131).  library_id=None loads the plain file name and
+    passes plugin_args as they are."""
+    cmd = [MINI_HARNESS_PATH, "-i", kfd_path, "-load", library + ("=" + library_id if library_id else "")]
     if frame_limit:
         cmd += ["-fl", str(frame_limit)]
-    cmd += list(plugin_args)
+    cmd += plugin_options_with_id(plugin_args, library_id)
     return subprocess.run(cmd, capture_output=True, text=True, timeout=timeout)
 
 

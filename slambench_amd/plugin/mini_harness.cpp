@@ -42,6 +42,8 @@
 #include <cstring>
 #include <fstream>
 #include <iomanip>
+#include <iostream>
+#include <map>
 #include <string>
 #include <vector>
 
@@ -55,12 +57,50 @@ namespace sio = slambench::io;
         std::exit(1);                                                                           \
     }
 
-static bool parse_plugin_options(SLAMBenchLibraryHelper *lib, const std::vector<std::string> &args) {
+// The option table, built the way the reference builds it (framework/shared/src/ParameterManager.cpp:102-141): first
+// the harness's own options (framework/shared/src/SLAMBenchConfiguration.cpp:67-76,
+// framework/tools/loaders/slambench_app.cpp:26-29), then the library's in the order in which it declared them, each
+// under "<id>-<name>" when the library was loaded as file.so=id (framework/shared/include/Parameters.h:152-153).  A
+// long or short name that is already taken ends the registration of that library's options there and then: what it
+// declared before stays, what it declared after is unknown to the command line.  The kfusion use-case's "-s"
+// (volume-size) meets the harness's "-s" (start-frame) that way.
+struct OptionTable {
+    std::map<std::string, Parameter *> long_options, short_options;     // harness-owned names map to nullptr
+    OptionTable() {
+        for (const char *n : {"frame-limit", "start-frame", "log-file", "input", "load-slam-library", "save-groundtruth", "dse",
+                              "help", "realtime-mode", "realtime-multiplier", "file-output", "alignment-technique", "gui", "lifelong"})
+            long_options[n] = nullptr;
+        for (const char *n : {"fl", "s", "o", "i", "load", "sgt", "dse", "h", "realtime", "realtime-mult", "fo", "a", "gui", "ll"})
+            short_options[n] = nullptr;
+    }
+    bool add_library(SLAMBenchLibraryHelper *lib, const std::string &prefix) {
+        for (Parameter *p : lib->getParameters()) {
+            if (!p->getLongOption().empty()) {
+                const std::string name = prefix + p->getLongOption();
+                if (long_options.count(name)) { std::cerr << "*** Duplicated long option replaced: '" << name << "'" << std::endl; return false; }
+                long_options[name] = p;
+            }
+            if (!p->getShortOption().empty()) {
+                const std::string name = prefix + p->getShortOption();
+                if (short_options.count(name)) { std::cerr << "*** Duplicated short option replaced: '" << name << "'" << std::endl; return false; }
+                short_options[name] = p;
+            }
+        }
+        return true;
+    }
+};
+
+static bool parse_plugin_options(const OptionTable &table, const std::vector<std::string> &args) {
     for (size_t i = 0; i < args.size(); ++i) {
         const std::string &a = args[i];
         Parameter *hit = nullptr;
-        for (Parameter *p : lib->getParameters())
-            if (a == "-" + p->getShortOption() || a == "--" + p->getLongOption()) hit = p;
+        if (a.size() > 2 && a[0] == '-' && a[1] == '-') {
+            auto it = table.long_options.find(a.substr(2));
+            if (it != table.long_options.end()) hit = it->second;
+        } else if (a.size() > 1 && a[0] == '-') {
+            auto it = table.short_options.find(a.substr(1));
+            if (it != table.short_options.end()) hit = it->second;
+        }
         if (!hit) { std::fprintf(stderr, "unknown option %s\n", a.c_str()); return false; }
         if (hit->requiresValue()) {
             if (i + 1 >= args.size()) { std::fprintf(stderr, "option %s needs a value\n", a.c_str()); return false; }
@@ -73,7 +113,7 @@ static bool parse_plugin_options(SLAMBenchLibraryHelper *lib, const std::vector<
 }
 
 int main(int argc, char **argv) {
-    std::string input, library, log_file, dump_frames;
+    std::string input, library, library_id, log_file, dump_frames;
     int frame_limit = 0, start_frame = 0;
     bool dse = false, reference_counting = false;
     std::vector<std::string> plugin_args;
@@ -81,7 +121,12 @@ int main(int argc, char **argv) {
         const std::string a = argv[i];
         auto need = [&](const char *what) { if (i + 1 >= argc) { std::fprintf(stderr, "%s needs a value\n", what); std::exit(1); } return std::string(argv[++i]); };
         if (a == "-i" || a == "--input") input = need("-i");
-        else if (a == "-load" || a == "--load-library") library = need("-load");
+        else if (a == "-load" || a == "--load-library" || a == "--load-slam-library") {
+            // file.so or file.so=identifier (framework/shared/include/SLAMBenchConfiguration.h:180-187)
+            library = need("-load");
+            const size_t eq = library.find('=');
+            if (eq != std::string::npos) { library_id = library.substr(eq + 1); library = library.substr(0, eq); }
+        }
         else if (a == "-o" || a == "--log-file") log_file = need("-o");
         else if (a == "-fl" || a == "--frame-limit") frame_limit = std::atoi(need("-fl").c_str());
         else if (a == "-s" || a == "--start-frame") start_frame = std::atoi(need("-s").c_str());
@@ -246,11 +291,14 @@ int main(int argc, char **argv) {
     }
     dlerror();
     if (!lib->c_sb_new_slam_configuration(lib)) { std::fprintf(stderr, "Configuration construction failed.\n"); return 1; }
-    if (!parse_plugin_options(lib, plugin_args)) return 1;
+    const std::string option_prefix = library_id.empty() ? "" : library_id + "-";
+    OptionTable options;
+    options.add_library(lib, option_prefix);
+    if (!parse_plugin_options(options, plugin_args)) return 1;
     if (dse) {                          // SLAMBenchConfiguration::PrintDse: the parameter space of the loaded library
-        std::cout << "libs:" << lib->GetIdentifier() << "\n";
+        std::cout << "libs:" << (library_id.empty() ? lib->GetIdentifier() : library_id) << "\n";
         for (Parameter *p : lib->getParameters())
-            std::cout << "argument:" << p->getLongOption() << "\n" << p->getStrDetails() << "\n";
+            std::cout << "argument:" << option_prefix << p->getLongOption() << "\n" << p->getStrDetails() << "\n";
         return 0;
     }
 
@@ -266,7 +314,7 @@ int main(int argc, char **argv) {
              << d->Intrinsics[2] << "," << d->Intrinsics[3] << "\n";
         *log << d->getName() << "-disparity-params: " << d->DisparityParams[0] << "," << d->DisparityParams[1] << "\n";
     }
-    for (Parameter *p : lib->getParameters()) *log << p->getLongOption() << ": " << p->getStrValue() << "\n";
+    for (Parameter *p : lib->getParameters()) *log << option_prefix << p->getLongOption() << ": " << p->getStrValue() << "\n";
 
     // ---- InitAlgorithms ----
     if (!lib->c_sb_init_slam_system(lib)) { std::fprintf(stderr, "Algorithm initialization failed.\n"); return 1; }

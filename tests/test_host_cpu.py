@@ -520,3 +520,39 @@ def test_sweep_scheduler_keeps_one_process_per_gpu(tmp_path):
     assert all(r.stdout.split()[0] == str(r.gpu) for r in res)
     bad = dse.run_sweep([{}], lambda pt: [sys.executable, "-c", "import sys; sys.exit(3)"], gpus=[0])
     assert bad[0].returncode == 3 and bad[0].summary == {}
+
+
+def test_plugin_options_behind_the_harness_own_dash_s_need_a_library_identifier(tmp_path):
+    """The reference's option table stops registering a library's options at the first name that is already taken
+    (framework/shared/src/ParameterManager.cpp:115-131), and the harness owns "-s" (start-frame,
+    framework/shared/src/SLAMBenchConfiguration.cpp:68): loaded as a plain file name, the plugin keeps the options it
+    declared before volume-size ("-s") and loses -d, -v, -y1..3 and --devices, short and long.  Loaded as
+    file.so=kf every option exists as -kf-x / --kf-name.  (`--dse` stops before anything needs a GPU.)"""
+    from slambench_amd import harness, synth
+    depth, gt, ts = synth.make_sequence(1, seed=1)
+    path = str(tmp_path / "s.kfd")
+    harness.write_kfd(path, depth, ts, (481.2, 480.0, 319.5, 239.5))
+
+    def run(args, library_id):
+        return harness.run_mini_harness(path, ["--dse"] + args, library_id=library_id)
+
+    # no identifier: declared before "-s" -> known; the long name of volume-size went in before its short name collided
+    for args in (["-c", "2"], ["--mu", "0.2"], ["--volume-size", "4,4,4"]):
+        r = run(args, None)
+        assert r.returncode == 0, (args, r.stderr)
+        assert "*** Duplicated short option replaced: 's'" in r.stderr
+    # ... and everything declared after it is gone
+    for args in (["-d", "2,2,2"], ["-v", "128"], ["--volume-resolution", "128"], ["-y1", "5"], ["--pyramid-level3", "2"],
+                 ["--devices", "2"]):
+        r = run(args, None)
+        assert r.returncode == 1 and "unknown option " + args[0] in r.stderr, (args, r.stderr)
+    # "-s" itself is the harness's start-frame, not the plugin's volume-size
+    r = run(["-s", "4,4,4"], None)
+    assert r.returncode == 0 and "default:8,8,8" in r.stdout
+    # with an identifier nothing collides
+    r = run(["-v", "128", "-d", "2,2,2", "-y1", "5", "--devices", "2", "-s", "4"], "kf")
+    assert r.returncode == 0 and "Duplicated" not in r.stderr, r.stderr
+    assert r.stdout.startswith("libs:kf\n") and "argument:kf-volume-resolution" in r.stdout
+    # the plain names do not exist then
+    r = harness.run_mini_harness(path, ["--dse", "-v", "128"], library_id=None, library=harness.PLUGIN_PATH + "=kf")
+    assert r.returncode == 1 and "unknown option -v" in r.stderr

@@ -34,7 +34,7 @@ slamfile.write_depth_sequence(path, depth, ts, TUM_FR1_DEPTH_INTRINSICS, gt_pose
 log = path + ".log"
 v = "%d,%d,%d" % (a.volume, a.volume, a.volume)
 t0 = time.perf_counter()
-r = subprocess.run([harness.MINI_HARNESS_PATH, "-i", path, "-load", harness.PLUGIN_PATH, "-o", log, "-v", v],
+r = subprocess.run([harness.MINI_HARNESS_PATH, "-i", path, "-load", harness.PLUGIN_PATH + "=kf", "-o", log, "-kf-v", v],
                    capture_output=True, text=True, timeout=600)
 wall = time.perf_counter() - t0
 if r.returncode != 0:
