@@ -104,10 +104,14 @@ enum kfh_buffer {
     KFH_BUF_SCALED_DEPTH = 1,  /* float[h>>l][w>>l]      level l of the filtered pyramid */
     KFH_BUF_INPUT_VERTEX = 2,  /* float4[h>>l][w>>l]                                    */
     KFH_BUF_INPUT_NORMAL = 3,  /* float4[h>>l][w>>l]                                    */
-    KFH_BUF_MODEL_VERTEX = 4,  /* float4[h][w]           raycast output                 */
-    KFH_BUF_MODEL_NORMAL = 5,  /* float4[h][w]                                          */
+    KFH_BUF_MODEL_VERTEX = 4,  /* float4[h][w]           the raycast's vertex map.  The raycast itself only writes the packed map
+                                  (KFH_BUF_MODEL_TN); this map, KFH_BUF_MODEL_NORMAL and KFH_BUF_RAY_T are built from it
+                                  inside kfh_device_ptr / kfh_download, for the raycast that was last when that call was
+                                  made: a pointer kept across frames shows old maps; ask again after each raycast (a
+                                  per-frame device consumer should read KFH_BUF_MODEL_TN) */
+    KFH_BUF_MODEL_NORMAL = 5,  /* float4[h][w]           (see KFH_BUF_MODEL_VERTEX)     */
     KFH_BUF_VOLUME = 6,        /* short2[slab_z1-slab_z0][Y][X]                         */
-    KFH_BUF_RAY_T = 7,         /* float[h][w]            hit distance of the last raycast */
+    KFH_BUF_RAY_T = 7,         /* float[h][w]            hit distance of the last raycast (see KFH_BUF_MODEL_VERTEX) */
     KFH_BUF_BRICK_MARKS = 8,   /* uint8[Z/8][Y/8][X/8]   1: no voxel of the 8^3 brick (and one voxel past it per axis) has
                                   been below 26300/32766 since the last reset; the raycast skips such bricks with its
                                   coarse step.  Unsharded contexts only. */
@@ -268,8 +272,9 @@ int kfh_k_integrate(void *d_volume, const int32_t res[3], const float dim[3], in
  * kfh_k_integrate, but the work list of the two launches lives in a fixed 4 MiB + 512 B array in device memory
  * (one copy per device, kept until the process ends) instead of a per-call hipMalloc, the pose travels as a kernel
  * argument instead of a host-to-device copy, and the call returns without waiting: everything is queued on
- * `stream`.  Volumes whose work list exceeds the array (more than 524288 boxes of 64 x 4 x {16, 32, 64} voxels:
- * beyond 2048^3) are refused with KFH_ERR_INVALID_ARG.  All calls on one device share that device's array: calls
+ * `stream`.  The array holds 524288 work items of 8 bytes; a volume whose work list needs more is refused with
+ * KFH_ERR_INVALID_ARG (a 2048^3 volume with the default settings takes 1 MiB of the 4; the experiment settings
+ * KFH_INTEGRATE_GROUP and KFH_INTEGRATE_ZCHUNK change what a volume needs: a group of 1 at 2048^3 needs 8 MiB).  All calls on one device share that device's array: calls
  * that overlap on one device (different streams or threads) race; calls on one stream are safe back to back.
  * The first call on a device looks the array's address up (hipGetSymbolAddress); make it outside a capture. */
 int kfh_k_integrate_noalloc(void *d_volume, const int32_t res[3], const float dim[3], int z0, int z1,

@@ -543,6 +543,19 @@ static int track_impl(kfh_context *c, int share, int share_count, kfh_allreduce_
         a.max_blocks = c->compute_units;
         const bool sharded = allreduce != nullptr;      // a single share with a callback still takes the exchange path
         a.rows_reduced = sharded ? 1 : 0;
+        if (sharded) {
+            // every level must give every share at least one row of tiles: checked before anything is queued, so that
+            // a refusal leaves the context as it was
+            for (int level = 2; level >= 0; --level) {
+                int pw = 0, ppt = 0;
+                const int iw = c->w >> level, ih = c->h >> level;
+                track_shape(iw, ih, c->compute_units, &pw, &ppt);
+                const int tile_rows = track_blocks(iw, ih, pw, ppt) / ((iw + KFH_TRACK_TILE_W - 1) / KFH_TRACK_TILE_W);
+                if (tile_rows < share_count)
+                    return fail(KFH_ERR_INVALID_ARG, "pyramid level %d has %d tile rows, fewer than the %d shares", level,
+                                tile_rows, share_count);
+            }
+        }
         int seq = 0, rows = 0;
         const float *pending = nullptr;      // sharded: the all-reduced row the next launch solves
         for (int level = 2; level >= 0; --level) {
@@ -555,9 +568,6 @@ static int track_impl(kfh_context *c, int share, int share_count, kfh_allreduce_
             const int tiles_x = (a.iw + KFH_TRACK_TILE_W - 1) / KFH_TRACK_TILE_W;
             const int tile_rows = track_blocks(a.iw, a.ih, a.pw, a.ppt) / tiles_x;
             if (sharded) {
-                if (tile_rows < share_count)
-                    return fail(KFH_ERR_INVALID_ARG, "pyramid level %d has %d tile rows, fewer than the %d shares", level,
-                                tile_rows, share_count);
                 const int r0 = (int)((long long)share * tile_rows / share_count);
                 const int r1 = (int)((long long)(share + 1) * tile_rows / share_count);
                 a.block0 = r0 * tiles_x;
@@ -573,8 +583,17 @@ static int track_impl(kfh_context *c, int share, int share_count, kfh_allreduce_
                 if (sharded) {
                     float *row = c->d_reduced + (size_t)((seq + 1) & 1) * 64;
                     KFH_HIP(launch_sum_partials(row, a.partials_out, a.block_count, c->stream));
-                    if (int rc = allreduce(user, row, c->stream))
-                        return fail(KFH_ERR_STATE, "the all-reduce callback of kfh_track_rows failed with code %d", rc);
+                    if (int rc = allreduce(user, row, c->stream)) {
+                        // The frame cannot be tracked any further.  The iteration launches queued so far have left a
+                        // pending row in the ICP record; the skip launch ends the frame as "not tracked" (old pose
+                        // kept, record cleared, work lists emptied), so the context stays usable.
+                        FinishArgs skip = finish_args(c, 0, 0);
+                        attach_mail(c, &skip);
+                        (void)launch_track_skip(skip, c->stream);
+                        c->box_list_fresh = c->ray_list_fresh = true;
+                        return fail(KFH_ERR_STATE, "the all-reduce callback of kfh_track_rows failed with code %d; the "
+                                    "frame was ended as not tracked", rc);
+                    }
                     pending = row;
                     rows = 1;
                 } else {

@@ -47,8 +47,30 @@ def test_two_slabs_reproduce_the_full_volume(torch_cuda):
                 assert np.array_equal(got_n[..., :3], want[..., 1:])
                 nc = got_n
                 vc = slabs[0].download(native.BUF_MODEL_VERTEX)
-                # the vertex map is rebuilt from the hit distance: zero where nothing was hit
+                # the vertex map is rebuilt from the hit distance: zero where nothing was hit, and elsewhere
+                # origin + direction * t of the view the raycast used (pose * inverse camera matrix), restated here
+                # in float32 operation by operation
                 assert np.array_equal((vc[..., :3] != 0).any(-1) | (want[..., 0] == 0), np.ones(want.shape[:2], bool))
+                f32 = np.float32
+                pose = slabs[0].pose.astype(f32)            # the pose frame 3 was raycast from
+                fx, fy, cx, cy = [f32(v) / f32(slabs[0].cfg.compute_size_ratio) for v in slabs[0].cfg.intrinsics]
+                kinv = np.array([[f32(1) / fx, 0, -cx / fx, 0], [0, f32(1) / fy, -cy / fy, 0], [0, 0, 1, 0], [0, 0, 0, 1]], f32)
+                view = np.zeros((4, 4), f32)
+                for r in range(4):
+                    for col in range(4):
+                        acc = pose[r, 0] * kinv[0, col]
+                        for k in range(1, 4):
+                            acc = f32(acc + f32(pose[r, k] * kinv[k, col]))
+                        view[r, col] = acc
+                ys, xs = np.mgrid[0:h, 0:w].astype(f32)
+                t = want[..., 0]
+                want_v = np.zeros((h, w, 3), f32)
+                for r in range(3):
+                    direction = (view[r, 0] * xs + view[r, 1] * ys) + view[r, 2] * f32(1)
+                    want_v[..., r] = view[r, 3] + direction * t
+                hit = t > 0
+                assert hit.sum() > 1000
+                assert np.array_equal(vc[..., :3][hit].view(np.uint32), want_v[hit].view(np.uint32))
                 # first raycast: same volume, same pose -> the composited map is the single-device map except
                 # where a ray's step state restarts at the slab boundary
                 v_full = full.download(native.BUF_MODEL_VERTEX)[..., :3]
