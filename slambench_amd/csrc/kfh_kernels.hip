@@ -1881,6 +1881,18 @@ __global__ __launch_bounds__(256) void k_integrate_plan(IntegrateArgs a) {
 // and the update either takes the free-space shortcut on the raw word (value 32766 stays, weight + 1 capped) or the
 // reference's expression sequence.
 // -----------------------------------------------------------------------------------------------------
+// cache policy bits of the voxel loads and stores of the two-column march (gfx950: 1 = sc0, 2 = nt, 16 = sc1)
+#ifndef KFH_VOX_LOAD_AUX
+#define KFH_VOX_LOAD_AUX 0
+#endif
+#ifndef KFH_VOX_STORE_AUX
+#define KFH_VOX_STORE_AUX 0
+#endif
+// segments a wavefront pair cuts its planes into (the first one rotates from launch to launch); dense 512^3 work
+// launch with 1 / 2 / 4 / 8 segments: 237 / 221 / 223 / 232 us (more segments replay more additions)
+#ifndef KFH_INTEGRATE_SEGMENTS
+#define KFH_INTEGRATE_SEGMENTS 2
+#endif
 #ifndef KFH_INTEGRATE_V2U
 #define KFH_INTEGRATE_V2U 8
 #endif
@@ -1937,7 +1949,7 @@ __device__ inline void integrate_clear_marks(const IntegrateArgs &a, int x, int 
 // to [zlo, zhi).  Returns the number of voxels it stored (diagnostics).
 __device__ inline unsigned integrate_item_inside2(const IntegrateArgs &a, const Mat4 &invTrack, const Mat4 &K, f3 delta,
                                                   f3 cameraDelta, int x, int y, int first_bz, unsigned item_mask,
-                                                  int zlo, int zmid, int zhi, bool upper_first) {
+                                                  int zlo, int zhi, int segments, int first_segment) {
     const int sx = a.sx, sy = a.sy, sz = a.sz;
     const float mu = a.mu;
     const bool in_vol = x < sx && y < sy;                  // sx is even: x + 1 < sx as well
@@ -1989,7 +2001,7 @@ __device__ inline unsigned integrate_item_inside2(const IntegrateArgs &a, const 
     // request the voxels of the u-th plane of the batch at zi (a plane past the end of the run is never stored: its
     // load re-reads the run's last plane)
     auto request = [&](int u, int zi) {
-        const v2u v = __builtin_amdgcn_raw_buffer_load_b64(vol_rsrc, col, (unsigned)min(u, ze - 1 - zi) * plane_bytes, 0);
+        const v2u v = __builtin_amdgcn_raw_buffer_load_b64(vol_rsrc, col, (unsigned)min(u, ze - 1 - zi) * plane_bytes, KFH_VOX_LOAD_AUX);
         raw[u] = make_uint2(v.x, v.y);
     };
     // project the plane the sums stand at into slot u, request its depth pixels, advance the sums
@@ -2037,18 +2049,20 @@ __device__ inline unsigned integrate_item_inside2(const IntegrateArgs &a, const 
     auto store = [&](int u, int z) {
         // free space seen often enough stays at (1, maxweight): nothing to store then
         if (in_vol & (z < ze) & ((out[u].x != raw[u].x) | (out[u].y != raw[u].y))) {
-            __builtin_amdgcn_raw_buffer_store_b64(v2u{out[u].x, out[u].y}, vol_rsrc, col, (unsigned)u * plane_bytes, 0);
+            __builtin_amdgcn_raw_buffer_store_b64(v2u{out[u].x, out[u].y}, vol_rsrc, col, (unsigned)u * plane_bytes, KFH_VOX_STORE_AUX);
             if (KFH_STAMPS_COMPILED) written += (out[u].x != raw[u].x) + (out[u].y != raw[u].y);
         }
     };
 
-    // The planes [zlo, zhi) are taken as two segments, [zlo, zmid) and [zmid, zhi); with `upper_first` the upper one
-    // comes first (its sums are reached by replaying the additions, and the lower one starts over from plane 0).
-    // A launch that starts with the planes the launch before it touched last finds part of them in the memory-side
-    // cache, which holds about half of a 512^3 volume.
-    for (int pass = 0; pass < 2; ++pass) {
-    const bool upper = (pass == 0) == upper_first;
-    const int clo = upper ? zmid : zlo, chi = upper ? zhi : zmid;
+    // The planes [zlo, zhi) are taken as `segments` equal segments (cut at box boundaries), starting with segment
+    // `first_segment` and going round: a launch that starts with the segment the launch before it ended with finds
+    // those planes in the memory-side cache, which holds about half of a 512^3 volume.  A segment that does not
+    // follow its predecessor in z reaches its sums by replaying the additions (from plane 0 when it lies below).
+    const int seg_planes = ((zhi - zlo + segments - 1) / segments + a.zchunk - 1) / a.zchunk * a.zchunk;
+    for (int pass = 0; pass < segments; ++pass) {
+    const int seg = (first_segment + pass) % segments;
+    const int clo = zlo + seg * seg_planes, chi = min(zhi, clo + seg_planes);
+    if (clo >= chi) continue;
     unsigned mask = item_mask;
     while (mask) {
         // a run of boxes that follow each other without a gap
@@ -2103,8 +2117,8 @@ __global__ __launch_bounds__(256, KFH_INTEGRATE_MIN_WAVES) void k_integrate(Inte
         }
     }
     if (nbox == 0) return;
-    // launches with an open gate so far (the plan launch has counted this one): odd or even
-    const bool launch_parity = a.totals ? (__builtin_amdgcn_readfirstlane((unsigned)a.totals[1]) & 1u) != 0u : false;
+    // launches with an open gate so far (the plan launch has counted this one)
+    const unsigned launch_number = a.totals ? __builtin_amdgcn_readfirstlane((unsigned)a.totals[1]) : 0u;
     // diagnostics (dbg != null): per box and wavefront {start, end} of the 100 MHz counter, candidates, written
     const Mat4 invTrack = *a.inv_track;
     const int sx = a.sx, sy = a.sy, sz = a.sz, w = a.w;
@@ -2141,16 +2155,17 @@ __global__ __launch_bounds__(256, KFH_INTEGRATE_MIN_WAVES) void k_integrate(Inte
                 zsplit = zc0 + ((zc1 - zc0 + 1) / 2 + V2U - 1) / V2U * V2U;
             }
             const bool second = wv >= 2;
-            // each of the two takes its planes as two segments (split at a box boundary; short items are not split),
-            // in an order that alternates from launch to launch
+            // each of the two takes its planes in segments, starting with another one from launch to launch
             const int span_lo = max(a.z0, (ifirst + __ffs(imask) - 1) * a.zchunk);
             const int span_hi = min(a.z1, (ifirst + 32 - __clz(imask)) * a.zchunk);
             const int zlo = second ? max(zsplit, span_lo) : span_lo, zhi = second ? span_hi : min(zsplit, span_hi);
-            const int zmid = zhi - zlo >= 4 * a.zchunk ? zlo + (zhi - zlo) / (2 * a.zchunk) * a.zchunk : zhi;
+            // (short items are not cut up: a segment is at least two boxes)
+            const int segments = min(KFH_INTEGRATE_SEGMENTS, max(1, (zhi - zlo) / (2 * a.zchunk)));
+            const int first_segment = (segments - (int)(launch_number % (unsigned)segments)) % segments;
             const unsigned stored =
                 integrate_item_inside2(a, invTrack, K, delta, cameraDelta, bx * BOX_X + (lane % (BOX_X / 2)) * 2,
                                        by * BOX_Y + (wv & 1) * (BOX_Y / 2) + lane / (BOX_X / 2), ifirst, imask,
-                                       zlo, zmid, zhi, launch_parity);
+                                       zlo, zhi, segments, first_segment);
             if (a.dbg) {
                 unsigned long long tot = stored;
                 for (int m = 32; m >= 1; m >>= 1) tot += __shfl_xor(tot, m, 64);
