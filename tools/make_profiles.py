@@ -44,7 +44,7 @@ def kernel_summary(d, frames):
         out.append("%-28s %7s %10.2f %10.1f %6.1f %9.1f %9.1f" % (
             short(r["Name"])[-28:], r["Calls"], int(r["TotalDurationNs"]) / 1e6, float(r["AverageNs"]) / 1e3,
             100 * int(r["TotalDurationNs"]) / tot, int(r["MinNs"]) / 1e3, int(r["MaxNs"]) / 1e3))
-    upload = sum(int(r["TotalDurationNs"]) for r in rows if "upload" in short(r["Name"]))
+    upload = sum(int(r["TotalDurationNs"]) for r in rows if short(r["Name"]) in ("k_stage_copy", "__amd_rocclr_copyBuffer"))
     out.append("total kernel time %.2f ms; %.1f us per frame over %d frames (%.1f us without the upload kernels of "
                "the host-frame leg)" % (tot / 1e6, tot / frames / 1e3, frames, (tot - upload) / frames / 1e3))
     return f, "\n".join(out) + "\n"
