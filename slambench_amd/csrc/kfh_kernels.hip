@@ -1823,12 +1823,23 @@ __global__ __launch_bounds__(256) void k_integrate_plan(IntegrateArgs a) {
     const int lane = threadIdx.x & 63;
     unsigned gm = 0u, ge = 0u, off_h = 0u, off_t = 0u;
     unsigned long long heavy_mask = 0ull, light_mask = 0ull;
-    bool leader = false, heavy = false;
+    bool leader = false, heavy = false, paired = false;
     if (m) {
         gm = (unsigned)((m >> (lane & ~(G - 1))) & ((1ull << G) - 1ull));
         // an item whose surviving boxes are all of the "inside the image" kind says so (bit 28)
         ge = (unsigned)((__ballot(edge) >> (lane & ~(G - 1))) & ((1ull << G) - 1ull));
         leader = r == 0 && gm != 0u;
+        // Two items side by side in x (an even box column and the next one, whose groups sit G lanes apart in this
+        // wavefront) with the same surviving boxes, all of the inside kind, trade halves (bit 29 in both): the even
+        // one takes the first planes of both footprints, the odd one the rest, so that a wavefront marches whole
+        // 512-byte rows of the volume.
+        if (BOX_X == 64 && G <= 32 && a.vec2) {
+            const bool odd = (bx & 1) != 0;
+            const int peer = (odd ? lane - G : lane + G) & 63;
+            const unsigned gm_peer = __shfl(gm, peer, 64), ge_peer = __shfl(ge, peer, 64);
+            const bool peer_here = odd ? lane >= G : (lane + G < 64 && bx + 1 < a.gx);
+            paired = peer_here && ge == 0u && ge_peer == 0u && gm_peer == gm && __popc(gm) >= 2;
+        }
         const unsigned long long lm = __ballot(leader);
         const int first = __ffsll((long long)lm) - 1;
         // An item's cost grows with the planes it marches and, more slowly, with the planes it replays first.  Items in
@@ -1861,7 +1872,8 @@ __global__ __launch_bounds__(256) void k_integrate_plan(IntegrateArgs a) {
         const unsigned at = heavy ? base_heavy + off_h + __popcll(heavy_mask & below)
                                   : a.list_capacity - 1u - (base_light + off_t + __popcll(light_mask & below));
         a.boxes[at] =
-            make_uint2((unsigned)bx | ((unsigned)by << 8) | ((unsigned)(g * G) << 20) | (ge == 0u ? 1u << 28 : 0u), gm);
+            make_uint2((unsigned)bx | ((unsigned)by << 8) | ((unsigned)(g * G) << 20) | (ge == 0u ? 1u << 28 : 0u) |
+                       (paired ? 1u << 29 : 0u), gm);
     }
 }
 
@@ -2157,18 +2169,23 @@ __global__ __launch_bounds__(256, KFH_INTEGRATE_MIN_WAVES) void k_integrate(Inte
                 const int zc0 = max(a.z0, bz * a.zchunk), zc1 = min(a.z1, (bz + 1) * a.zchunk);
                 zsplit = zc0 + ((zc1 - zc0 + 1) / 2 + V2U - 1) / V2U * V2U;
             }
-            const bool second = wv >= 2;
+            // (an item that trades halves with its neighbour in x: each wavefront takes one row of both footprints,
+            // 128 columns, over the first planes (even box column) or the rest (odd one))
+            const bool wide = __builtin_amdgcn_readfirstlane((item.x >> 29) & 1u) != 0u;
+            const bool second = wide ? (bx & 1) != 0 : wv >= 2;
             // each of the two takes its planes in segments, starting with another one from launch to launch
             const int span_lo = max(a.z0, (ifirst + __ffs(imask) - 1) * a.zchunk);
             const int span_hi = min(a.z1, (ifirst + 32 - __clz(imask)) * a.zchunk);
-            const int zlo = second ? max(zsplit, span_lo) : span_lo, zhi = second ? span_hi : min(zsplit, span_hi);
+            const int zlo = second ? max(zsplit, span_lo) : span_lo;
+            const int zhi = second ? span_hi : min(zsplit, span_hi);
             // (short items are not cut up: a segment is at least two boxes)
             const int segments = min(KFH_INTEGRATE_SEGMENTS, max(1, (zhi - zlo) / (2 * a.zchunk)));
             const int first_segment = (segments - (int)(launch_number % (unsigned)segments)) % segments;
             const unsigned stored =
-                integrate_item_inside2(a, invTrack, K, delta, cameraDelta, bx * BOX_X + (lane % (BOX_X / 2)) * 2,
-                                       by * BOX_Y + (wv & 1) * (BOX_Y / 2) + lane / (BOX_X / 2), ifirst, imask,
-                                       zlo, zhi, segments, first_segment);
+                integrate_item_inside2(a, invTrack, K, delta, cameraDelta,
+                                       wide ? (bx & ~1) * BOX_X + lane * 2 : bx * BOX_X + (lane % (BOX_X / 2)) * 2,
+                                       wide ? by * BOX_Y + wv : by * BOX_Y + (wv & 1) * (BOX_Y / 2) + lane / (BOX_X / 2),
+                                       ifirst, imask, zlo, zhi, segments, first_segment);
             if (a.dbg) {
                 unsigned long long tot = stored;
                 for (int m = 32; m >= 1; m >>= 1) tot += __shfl_xor(tot, m, 64);

@@ -207,6 +207,27 @@ __global__ __launch_bounds__(256) void k_pipe(unsigned *vol, int V, const float 
     }
 }
 
+// Plain loop (U loads, U stores) on tiles of 128 x ROWS columns, two columns per lane, one row per wavefront, blocks of
+// ROWS wavefronts (HALVES = 0) or of 2 * ROWS wavefronts of which the second set marches the upper half of the planes.
+template <int ROWS, int HALVES, int U>
+__global__ void k_tile128(unsigned *vol, int V) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int tiles_x = V / 128;
+    const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
+    const int x = tx * 128 + lane * 2, y = ty * ROWS + (wave % ROWS);
+    const size_t plane = (size_t)V * V;
+    const int half = HALVES ? wave / ROWS : 0;
+    const int n = HALVES ? V / 2 : V;
+    unsigned *p = vol + (size_t)half * (V / 2) * plane + (size_t)y * V + x;
+    for (int z = 0; z < n; z += U) {
+        uint2 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = *reinterpret_cast<const uint2 *>(p + (size_t)(z + u) * plane);
+#pragma unroll
+        for (int u = 0; u < U; ++u) *reinterpret_cast<uint2 *>(p + (size_t)(z + u) * plane) = bump(v[u], 0.f);
+    }
+}
+
 __global__ __launch_bounds__(256) void k_linear(uint4 *vol, size_t n16) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) {
         uint4 v = vol[i];
@@ -325,6 +346,13 @@ int main(int argc, char **argv) {
         us = time_us([&] { hipLaunchKernelGGL((k_roll<32, 1>), dim3(blocks), dim3(256), 0, 0, vol, V, table, par++); }, 15);
         printf("same, ALU32, halves swapped every launch   : %8.1f us  frac %.3f\n", us, 8.0 * n / us * 1e-6 / 8.0);
         CK(hipFree(table));
+    }
+    {
+        float us;
+#define TILE(ROWS, HALVES, U) \
+        us = time_us([&] { hipLaunchKernelGGL((k_tile128<ROWS, HALVES, U>), dim3((V / 128) * (V / ROWS)), dim3(64 * ROWS * (HALVES ? 2 : 1)), 0, 0, vol, V); }, 15); \
+        printf("tile 128 x %d, %s, U%d, plain loop : %8.1f us  frac %.3f\n", ROWS, HALVES ? "halves in one block" : "whole columns", U, us, 8.0 * n / us * 1e-6 / 8.0);
+        TILE(1, 0, 8) TILE(2, 0, 8) TILE(4, 0, 8) TILE(8, 0, 8) TILE(1, 1, 8) TILE(2, 1, 8) TILE(4, 1, 8) TILE(2, 0, 4) TILE(2, 1, 4) TILE(4, 0, 4)
     }
 #define RUN(VEC, WX, U, ALU, zrun, blocks) run<VEC, WX, U, ALU>(vol, V, zrun, blocks, "VEC" #VEC " WX" #WX " U" #U " ALU" #ALU)
     // the shape of the integrate kernel as it stands: 64 x 4 tile, a dword per lane, 8 planes in flight, whole columns
