@@ -88,7 +88,7 @@ def parse_args():
     ap.add_argument("--track-stats-csv", default=os.path.join(ROOT, "profiles", "r3_kernel_stats.csv"),
                     help="rocprofv3 --kernel-trace --stats table of this command (tools/profile_round.sh): source of "
                          "the per-level launch durations behind roofline_track")
-    ap.add_argument("--dense-traffic-json", default=os.path.join(ROOT, "profiles", "r2_dense_integrate.json"),
+    ap.add_argument("--dense-traffic-json", default=os.path.join(ROOT, "profiles", "r3_dense_integrate.json"),
                     help="counter bytes of the dense integration leg (tools/make_profiles.py --dense)")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "integrate_traffic.json"),
                     help="HBM bytes per integrate launch from the committed rocprofv3 PMC passes")
@@ -334,6 +334,7 @@ def zslab_leg(a, rank, world, dist, torch, backend, V, steps, solo=False):
         "voxel_updates_per_s": voxels / elapsed,
         "integrate_voxels_per_launch_all_ranks": vox_per_launch,
         "integrate_ms_slowest_rank": t_int * 1e3 if t_int > 0 else None,
+        "integrate_voxels_per_s_all_ranks": vox_per_launch / t_int if (n_int and t_int > 0) else None,
         "tracked_fraction": -neg_tracked / max(1, steps),
         "ate_rmse_m": ate_rmse,
         "roofline": {"kernel": "k_integrate_plan + k_integrate", "bound": "hbm", "achieved": achieved,
@@ -342,7 +343,8 @@ def zslab_leg(a, rank, world, dist, torch, backend, V, steps, solo=False):
                      "note": "8 B x the voxels of the boxes the work launches of ALL ranks took per integration / the "
                              "slowest rank's mean HIP-event duration of its two launches / (ranks x 8 TB/s)"},
         "note": "frames/s of a sharded sequence is bounded by what every rank repeats (preprocessing, tracking); "
-                "voxel_updates_per_s is the figure that grows with the ranks",
+                "integrate_voxels_per_s_all_ranks (voxels all ranks integrate per launch / the slowest rank's launch "
+                "time) is the figure that grows with the ranks; voxel_updates_per_s is voxels over wall time",
     }
 
 

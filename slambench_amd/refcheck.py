@@ -39,7 +39,9 @@ def dataset_roots():
     roots = []
     if os.environ.get("KFH_DATASET_DIR"):
         roots.append(os.environ["KFH_DATASET_DIR"])
-    roots += [os.path.join(os.getcwd(), "datasets"), os.path.join(os.path.dirname(_HERE), "datasets")]
+    for root in (os.path.join(os.getcwd(), "datasets"), os.path.join(os.path.dirname(_HERE), "datasets")):
+        if os.path.realpath(root) not in [os.path.realpath(r) for r in roots]:
+            roots.append(root)
     return roots
 
 

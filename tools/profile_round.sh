@@ -22,6 +22,7 @@ timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/dense
 timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/dense_write -o write -- python3 $R/tools/dense_leg.py > /dev/null 2> $OUT/dense_write.err
 cd $R
 timeout -k 10 300 python3 bench.py > $OUT/bench_default.json 2> $OUT/bench.err
+python3 tools/launch_gaps.py $OUT/kt > $OUT/integrate_launch_gaps.txt
 # the raw traces are large: keep the statistics and the counter tables
 find $OUT -name "*kernel_trace.csv" -delete
 ls -R $OUT | head -60
