@@ -79,6 +79,9 @@ def parse_args():
                          "sequence whose 2048^3 volume is sharded over the ranks), reported under zslab_<volume>")
     ap.add_argument("--zslab-steps", type=int, default=100, help="timed frames of the additional z-slab leg")
     ap.add_argument("--no-zslab-leg", action="store_true", help="N>1, replicas: skip the additional z-slab leg")
+    ap.add_argument("--zslab-timeout", type=float, default=150.0,
+                    help="seconds after which rank 0 prints the line without a z-slab result and exits with status 4 "
+                         "(below --pg-timeout, which aborts the process)")
     ap.add_argument("--pg-timeout", type=float, default=180.0,
                     help="seconds after which a collective that does not complete ends the run (non-zero exit)")
     ap.add_argument("--dataset", default="auto",
@@ -676,12 +679,29 @@ def main():
         if rank == 0:       # should the sharded leg end the job, the replica line is at least in the log
             sys.stderr.write("bench.py: replica leg done: " + json.dumps({k: result[k] for k in ("value", "n_gpus", "ms_per_step")}) + "\n")
         torch.cuda.empty_cache()
+        watchdog = None
+        if rank == 0:
+            # a sharded leg that hangs (a collective that never completes) must not take the replica result with it:
+            # before the process group's own timeout aborts the process, the line goes out with the failure in it
+            import threading
+
+            def give_up():
+                result["zslab_%d" % a.zslab_volume] = {"error": "no result within %d s" % a.zslab_timeout}
+                print(json.dumps(result))
+                sys.stdout.flush()
+                os._exit(4)
+
+            watchdog = threading.Timer(a.zslab_timeout, give_up)
+            watchdog.daemon = True
+            watchdog.start()
         try:
             leg = zslab_leg(a, rank, world, dist, torch, backend, a.zslab_volume, a.zslab_steps)
         except Exception as exc:            # the line still goes out, with the failure in it, and the run fails
             leg_failed = True
             leg = {"error": "%s: %s" % (type(exc).__name__, exc)}
             sys.stderr.write("bench.py: rank %d: z-slab leg failed: %s\n" % (rank, leg["error"]))
+        if watchdog is not None:
+            watchdog.cancel()
         if rank == 0:
             result["zslab_%d" % a.zslab_volume] = leg
     if world > 1 or solo_exchange:
