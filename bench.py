@@ -79,10 +79,10 @@ def parse_args():
                          "sequence whose 2048^3 volume is sharded over the ranks), reported under zslab_<volume>")
     ap.add_argument("--zslab-steps", type=int, default=100, help="timed frames of the additional z-slab leg")
     ap.add_argument("--no-zslab-leg", action="store_true", help="N>1, replicas: skip the additional z-slab leg")
-    ap.add_argument("--zslab-timeout", type=float, default=150.0,
+    ap.add_argument("--zslab-timeout", type=float, default=240.0,
                     help="seconds after which rank 0 prints the line without a z-slab result and exits with status 4 "
                          "(below --pg-timeout, which aborts the process)")
-    ap.add_argument("--pg-timeout", type=float, default=180.0,
+    ap.add_argument("--pg-timeout", type=float, default=300.0,
                     help="seconds after which a collective that does not complete ends the run (non-zero exit)")
     ap.add_argument("--dataset", default="auto",
                     help="compare the plugin with the reference's published kfusion-cpp log on a dataset file "

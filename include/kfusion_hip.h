@@ -222,7 +222,10 @@ int kfh_track_rows(kfh_context *ctx, int share, int share_count, kfh_allreduce_f
  * member's segment map - its own memory and its peers', read over the links after hipDeviceEnablePeerAccess; nothing
  * is copied and no collective library is involved.  The devices order themselves by events; the calling thread only
  * queues.  Results are those of kfh_raycast_slab + an all-gather + kfh_composite_slabs, bit for bit.
- * A group of one member is a plain context.  At most 16 members; calls on one group must not overlap. */
+ * A group of one member is a plain context.  At most 16 members; calls on one group must not overlap.
+ * When the members sit on more than one device, kfh_group_process_frame queues each member's launches from a host
+ * thread of that member (created with the group, joined twice per frame); KFH_GROUP_THREADS=0 / 1 in the
+ * environment at creation decides otherwise. */
 typedef struct kfh_group kfh_group;
 int kfh_group_create(const kfh_config *cfg, const int *devices, int n, kfh_group **out);
 int kfh_group_destroy(kfh_group *group);

@@ -12,6 +12,9 @@
 #include <mutex>
 #include <new>
 #include <string>
+#include <condition_variable>
+#include <functional>
+#include <thread>
 #include <vector>
 
 using namespace kfh;
@@ -1271,11 +1274,75 @@ int kfh_k_integrate(void *d_volume, const int32_t res[3], const float dim[3], in
 // between the devices is by events: a member composites when all marches of the frame are done, and marches the
 // next frame's segments when all composites of this frame are done.
 // ------------------------------------------------------------------------------------------------------
+namespace {
+// One host thread per group member, so that the members' launches of a frame (25 each) are queued side by side instead
+// of one member after the other.  run(job) hands job(i) to thread i and returns when all have finished: the first
+// non-zero result, with that thread's error text as the caller's.
+struct GroupWorkers {
+    std::vector<std::thread> threads;
+    std::mutex lock;
+    std::condition_variable go, done;
+    std::function<int(int)> job;
+    std::vector<int> result;
+    std::vector<std::string> text;
+    unsigned generation = 0;
+    int pending = 0;
+    bool stop = false;
+
+    void start(int n, const std::vector<int> &device) {
+        result.assign(n, 0);
+        text.assign(n, std::string());
+        for (int i = 0; i < n; ++i) threads.emplace_back([this, i, dev = device[i]] { loop(i, dev); });
+    }
+    void loop(int i, int device) {
+        (void)hipSetDevice(device);
+        unsigned seen = 0;
+        for (;;) {
+            std::function<int(int)> mine;
+            {
+                std::unique_lock<std::mutex> hold(lock);
+                go.wait(hold, [&] { return stop || generation != seen; });
+                if (stop) return;
+                seen = generation;
+                mine = job;
+            }
+            const int rc = mine(i);
+            std::string why = rc != KFH_OK ? g_last_error : std::string();
+            std::lock_guard<std::mutex> hold(lock);
+            result[i] = rc;
+            text[i].swap(why);
+            if (--pending == 0) done.notify_one();
+        }
+    }
+    int run(const std::function<int(int)> &f) {
+        std::unique_lock<std::mutex> hold(lock);
+        job = f;
+        pending = (int)threads.size();
+        ++generation;
+        go.notify_all();
+        done.wait(hold, [&] { return pending == 0; });
+        for (size_t i = 0; i < result.size(); ++i)
+            if (result[i] != KFH_OK) return fail(result[i], "group member %zu: %s", i, text[i].c_str());
+        return KFH_OK;
+    }
+    void finish() {
+        {
+            std::lock_guard<std::mutex> hold(lock);
+            stop = true;
+        }
+        go.notify_all();
+        for (std::thread &t : threads) t.join();
+        threads.clear();
+    }
+};
+}  // namespace
+
 struct kfh_group {
     std::vector<kfh_context *> member;
     std::vector<float4 *> segments;          // per member: the packed map its slab march writes (on its device)
     std::vector<hipEvent_t> marched, composited;
     bool exchanged = false;                  // a composite has been queued since the group was created or reset
+    GroupWorkers *workers = nullptr;         // null: the calling thread queues every member's launches itself
 };
 
 namespace {
@@ -1287,6 +1354,11 @@ void slab_range(int res, int count, int index, int *z0, int *z1) {
 }
 
 void group_free(kfh_group *g) {
+    if (g->workers) {
+        g->workers->finish();
+        delete g->workers;
+        g->workers = nullptr;
+    }
     for (size_t i = 0; i < g->member.size(); ++i) {
         kfh_context *c = g->member[i];
         if (!c) continue;
@@ -1357,6 +1429,19 @@ int kfh_group_create(const kfh_config *cfg, const int *devices, int n, kfh_group
         group_free(g);
         return fail(rc, "%s", text.c_str());
     }
+    // A thread per member when the members sit on more than one device (on one device the launches share the
+    // device's command processor anyway); KFH_GROUP_THREADS=0 / 1 decides otherwise.
+    bool threaded = false;
+    for (int i = 1; i < n; ++i) threaded = threaded || devices[i] != devices[0];
+    if (const char *e = std::getenv("KFH_GROUP_THREADS")) threaded = std::atoi(e) != 0;
+    if (threaded && n > 1) {
+        g->workers = new (std::nothrow) GroupWorkers();
+        if (!g->workers) {
+            group_free(g);
+            return fail(KFH_ERR_STATE, "out of host memory");
+        }
+        g->workers->start(n, std::vector<int>(devices, devices + n));
+    }
     *out = g;
     return KFH_OK;
 }
@@ -1405,40 +1490,59 @@ int kfh_group_set_depth_device(kfh_group *g, const uint16_t *const *d_depth_per_
     return KFH_OK;
 }
 
+namespace {
+// What member i queues before the exchange: the frame up to its slab's ray segments.
+int group_member_first_half(kfh_group *g, int i, bool raycasts) {
+    const int n = (int)g->member.size();
+    kfh_context *c = g->member[i];
+    DeviceScope on_device(c->device);
+    if (int rc = kfh_preprocess(c)) return rc;
+    if (int rc = kfh_track(c)) return rc;
+    if (int rc = kfh_integrate(c)) return rc;
+    if (raycasts) {
+        // the march overwrites the map the peers composited from in the frame before
+        if (g->exchanged)
+            for (int j = 0; j < n; ++j)
+                if (j != i) KFH_HIP(hipStreamWaitEvent(c->stream, g->composited[j], 0));
+        if (int rc = raycast_slab_to(c, g->segments[i])) return rc;
+        KFH_HIP(hipEventRecord(g->marched[i], c->stream));
+    }
+    return KFH_OK;
+}
+
+// What member i queues once every member's `marched` event of this frame has been recorded on the host side.
+int group_member_second_half(kfh_group *g, int i, bool raycasts) {
+    const int n = (int)g->member.size();
+    kfh_context *c = g->member[i];
+    DeviceScope on_device(c->device);
+    if (raycasts) {
+        for (int j = 0; j < n; ++j)
+            if (j != i) KFH_HIP(hipStreamWaitEvent(c->stream, g->marched[j], 0));
+        c->model_maps_stale = true;
+        KFH_HIP(launch_composite_parts(c->d_ref_tn, g->segments.data(), n, c->w * c->h, c->stream));
+        KFH_HIP(hipEventRecord(g->composited[i], c->stream));
+    }
+    return kfh_end_frame(c);
+}
+}  // namespace
+
 int kfh_group_process_frame(kfh_group *g) {
     KFH_REQUIRE(g != nullptr, "group is NULL");
     const int n = (int)g->member.size();
     if (n == 1) return kfh_process_frame(g->member[0]);
     const bool raycasts = g->member[0]->frame > 2;
-    for (int i = 0; i < n; ++i) {
-        kfh_context *c = g->member[i];
-        DeviceScope on_device(c->device);
-        if (int rc = kfh_preprocess(c)) return rc;
-        if (int rc = kfh_track(c)) return rc;
-        if (int rc = kfh_integrate(c)) return rc;
-        if (raycasts) {
-            // the march overwrites the map the peers composited from in the frame before
-            if (g->exchanged)
-                for (int j = 0; j < n; ++j)
-                    if (j != i) KFH_HIP(hipStreamWaitEvent(c->stream, g->composited[j], 0));
-            if (int rc = raycast_slab_to(c, g->segments[i])) return rc;
-            KFH_HIP(hipEventRecord(g->marched[i], c->stream));
-        }
+    // Two rounds with a host-side join between them: a stream can only be told to wait for an event that has been
+    // recorded already, so every member's march must be queued before any member queues its composite.
+    if (g->workers) {
+        if (int rc = g->workers->run([g, raycasts](int i) { return group_member_first_half(g, i, raycasts); })) return rc;
+        if (int rc = g->workers->run([g, raycasts](int i) { return group_member_second_half(g, i, raycasts); })) return rc;
+    } else {
+        for (int i = 0; i < n; ++i)
+            if (int rc = group_member_first_half(g, i, raycasts)) return rc;
+        for (int i = 0; i < n; ++i)
+            if (int rc = group_member_second_half(g, i, raycasts)) return rc;
     }
-    if (raycasts) {
-        for (int i = 0; i < n; ++i) {
-            kfh_context *c = g->member[i];
-            DeviceScope on_device(c->device);
-            for (int j = 0; j < n; ++j)
-                if (j != i) KFH_HIP(hipStreamWaitEvent(c->stream, g->marched[j], 0));
-            c->model_maps_stale = true;
-            KFH_HIP(launch_composite_parts(c->d_ref_tn, g->segments.data(), n, c->w * c->h, c->stream));
-            KFH_HIP(hipEventRecord(g->composited[i], c->stream));
-        }
-        g->exchanged = true;
-    }
-    for (kfh_context *c : g->member)
-        if (int rc = kfh_end_frame(c)) return rc;
+    if (raycasts) g->exchanged = true;
     return KFH_OK;
 }
 

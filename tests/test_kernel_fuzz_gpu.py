@@ -112,6 +112,51 @@ def test_integrate_and_raycast_random_case(torch_cuda, seed):
     assert np.array_equal(n_got[hit].view(np.uint32), n_want[hit].view(np.uint32)), c
 
 
+def _draw_tall(seed):
+    """A thin volume of 512 to 2048 planes seen roughly along its z axis: columns that start metres away and end at (or
+    behind) the camera, with the image border cutting through the volume.  Long columns are where the marched
+    position sums drift furthest from the corner projections the box tests use."""
+    rng = np.random.default_rng(9100 + seed)
+    res = (int(rng.choice([64, 96, 128, 130, 192, 77])), int(rng.integers(4, 24)), int(rng.choice([512, 1024, 2048])))
+    dim = (float(rng.uniform(0.3, 1.5)), float(rng.uniform(0.05, 0.4)), float(rng.uniform(3.0, 8.0)))
+    w, h = int(rng.integers(64, 200)), int(rng.integers(48, 150))
+    cx, cy = 0.5 * dim[0], 0.5 * dim[1]
+    side = rng.integers(0, 3)
+    ez = -float(rng.uniform(0.05, 1.0)) if side == 0 else dim[2] + float(rng.uniform(0.05, 1.0)) if side == 1 else \
+        float(rng.uniform(0.0, dim[2]))
+    eye = np.array([cx + rng.uniform(-0.6, 0.6) * dim[0], cy + rng.uniform(-2.0, 2.0) * dim[1], ez])
+    far_end = dim[2] if (side == 0 or (side == 2 and rng.random() < 0.5)) else 0.0
+    target = np.array([cx + rng.uniform(-0.3, 0.3) * dim[0], cy + rng.uniform(-0.5, 0.5) * dim[1], far_end])
+    roll0 = rng.uniform(-np.pi, np.pi)
+    poses = [_look_at(eye + 0.004 * i, target - 0.01 * i, roll0 + 0.005 * i) for i in range(3)]
+    fx = w * float(rng.uniform(0.6, 1.6))               # long focal lengths: the volume overflows the image
+    k = (fx, fx * float(rng.uniform(0.95, 1.05)), 0.5 * w - 0.5 + float(rng.uniform(-3, 3)),
+         0.5 * h - 0.5 + float(rng.uniform(-3, 3)))
+    return dict(w=w, h=h, res=res, dim=dim, poses=poses, k=k, mu=float(rng.choice([0.05, 0.1, 0.3])),
+                scale=float(rng.choice([1000.0, 1500.0, 700.0])), seed=seed)
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("KFH_TALL_FUZZ_SEEDS", "8"))))
+def test_integrate_tall_columns_random_case(torch_cuda, seed):
+    torch = torch_cuda
+    L = native.lib()
+    c = _draw_tall(seed)
+    w, h, res, dim, mu = c["w"], c["h"], c["res"], c["dim"], c["mu"]
+    K = kf_ref.camera_matrix(c["k"])
+    res_c, dim_c = (C.c_int32 * 3)(*res), (C.c_float * 3)(*dim)
+    vol_ref = kf_ref.new_volume(res)
+    vol = torch.from_numpy(vol_ref.copy()).cuda()
+    for i, pose in enumerate(c["poses"]):
+        depth = kf_ref.mm2meters(make_depth(h, w, seed=seed * 5 + i, holes=0.05), w, h, c["scale"])
+        inv_pose = kf_ref.mat_inverse(pose)
+        kf_ref.integrate(vol_ref, dim, depth, inv_pose, K, mu, 100.0)
+        d = torch.from_numpy(depth).cuda()
+        native.check(L.kfh_k_integrate(vp(vol), res_c, dim_c, 0, res[2], vp(d), w, h, hp(m4(inv_pose)), hp(m4(K)),
+                                       mu, 100.0, None))
+    assert np.array_equal(vol.cpu().numpy(), vol_ref), c
+    _seen["tall"] = _seen.get("tall", 0) + int((vol_ref[..., 1] > 0).sum() > 500)
+
+
 @pytest.mark.parametrize("seed", range(int(os.environ.get("KFH_KERNEL_FUZZ_SEEDS", "12"))))
 def test_track_reduce_random_case(torch_cuda, seed):
     """trackKernel + reduceKernel on image sizes without any alignment (partial tiles of every block shape), input
@@ -220,6 +265,7 @@ def test_random_cases_were_not_vacuous(torch_cuda):
     assert _seen["fused"] >= 0.6 * _seen["cases"], _seen
     assert _seen["hit"] >= 0.4 * _seen["cases"], _seen
     assert _seen.get("tracked", 0) >= 0.6 * _seen["cases"], _seen
+    assert _seen.get("tall", 0) >= 4, _seen
 
 
 @pytest.mark.parametrize("res,dim", [((64, 64, 64), (4.0, 4.0, 4.0)), ((61, 45, 70), (4.0, 3.0, 5.0))])
