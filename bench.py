@@ -67,10 +67,12 @@ def parse_args():
     ap.add_argument("--icp", choices=["replicated", "allreduce"], default="replicated",
                     help="--mode zslab: every rank tracks the whole image (no collective), or every rank tracks its "
                          "rows and the 32 ICP sums are all-reduced per iteration")
-    ap.add_argument("--exchange", choices=["gather", "tiles"], default="gather",
+    ap.add_argument("--exchange", choices=["auto", "gather", "tiles"], default="auto",
                     help="--mode zslab: one all-gather of every rank's slab candidates (16 B per pixel and rank), or "
                          "an all-to-all that gives every rank the candidates of its 1/N of the image followed by an "
-                         "all-gather of the selected shares (2/N of the bytes, two collectives)")
+                         "all-gather of the selected shares (2/N of the bytes, two collectives); auto: the z-slab leg "
+                         "behind the replicas times a few frames of each and keeps the faster one, --mode zslab takes "
+                         "the all-gather")
     ap.add_argument("--force-exchange", action="store_true",
                     help="--mode zslab on ONE rank: still take the exchange path (slab march, all-gather, composite, "
                          "all-reduce) through a single-rank RCCL group, to time the collectives' fixed cost")
@@ -289,15 +291,43 @@ def zslab_leg(a, rank, world, dist, torch, backend, V, steps, solo=False):
     total = steps + untimed
     n_unique = max(8, min(40, total))
     depth, gt, ts = synth.make_sequence(n_unique, seed=1, intrinsics=TUM_FR1_DEPTH_INTRINSICS, noise=True)
-    order = ping_pong(n_unique, total)
+    order = ping_pong(n_unique, total + 96)
     d_depth = torch.from_numpy(depth.view(np.int16)).cuda()
     ptrs = [int(d_depth[i].data_ptr()) for i in range(n_unique)]
-    sharded = SlabKFusion(cfg, rank, world, dist, torch, icp=a.icp, force_exchange=solo, exchange=a.exchange)
+    can_tile = (640 * 480) % world == 0
+    exchange = a.exchange if a.exchange != "auto" else "gather"
+    sharded = SlabKFusion(cfg, rank, world, dist, torch, icp=a.icp, force_exchange=solo, exchange=exchange)
     kf = sharded.kf
     kf.set_timing(2)                    # every integration of this short leg is timed
     for i in range(untimed):
         sharded.process_frame(ptrs[order[i]])
     kf.sync()
+    probe = None
+    if a.exchange == "auto" and world > 1 and can_tile:
+        # which of the two exchanges is faster depends on the link rate and on the fixed cost of a collective at this
+        # rank count: a few frames of each, timed on all ranks, decide (the maps and poses are the same either way)
+        probe = {}
+        at = untimed                    # the stream simply goes on, so that the frames keep tracking
+        for mode in ("gather", "tiles", "gather", "tiles"):
+            sharded.exchange_mode = mode
+            for i in range(4):                                # buffers and communicators of the mode come up untimed
+                sharded.process_frame(ptrs[order[at + i]])
+            kf.sync()
+            dist.barrier()
+            tp = time.perf_counter()
+            for i in range(4, 20):
+                sharded.process_frame(ptrs[order[at + i]])
+            kf.sync()
+            at += 20
+            (t_mode,) = reduce_ranks([time.perf_counter() - tp], "max", dist, torch, backend, world)
+            probe[mode] = min(probe.get(mode, 1e9), t_mode / 16 * 1e3)
+        exchange = min(probe, key=probe.get)
+        sharded.exchange_mode = exchange
+        kf.reset()                      # the probe frames are not part of the sequence
+        kf.set_timing(2)
+        for i in range(untimed):
+            sharded.process_frame(ptrs[order[i]])
+        kf.sync()
     boxes0, launches0, voxels_per_box = kf.integrate_totals()
     if world > 1:
         dist.barrier()
@@ -330,8 +360,9 @@ def zslab_leg(a, rank, world, dist, torch, backend, V, steps, solo=False):
         "workload": "ONE synthetic 640x480 sequence, %d^3 TSDF over 8 m in %d z-slabs, ICP 10/5/4, integration-rate 2 "
                     "(BASELINE.json configs[3])" % (V, world),
         "volume": V, "ranks": world, "backend": backend, "icp": a.icp,
-        "exchange": "all-gather of the packed ray segments" if a.exchange == "gather" else
+        "exchange": "all-gather of the packed ray segments" if exchange == "gather" else
                     "all-to-all by image share + all-gather of the shares",
+        "exchange_probe_ms_per_frame": probe,
         "steps": steps, "frames_per_s": steps / elapsed, "ms_per_step": elapsed / steps * 1e3,
         "scaling": "strong",
         "voxel_updates_per_s": voxels / elapsed,
@@ -409,6 +440,8 @@ def main():
 
     if zslab:
         from slambench_amd.sharded import SlabKFusion
+        if a.exchange == "auto":
+            a.exchange = "gather"
         sharded = SlabKFusion(cfg, rank, world, dist, torch, icp=a.icp, force_exchange=solo_exchange,
                               exchange=a.exchange)
         kf = sharded.kf

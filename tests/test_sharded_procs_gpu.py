@@ -165,3 +165,8 @@ def test_bench_with_two_ranks_reports_the_replica_leg_and_the_zslab_leg(torch_cu
     assert roof["peak"] == 16000.0 and roof["achieved"] > 0 and 0 < roof["frac"] < 1
     # both ranks' boxes are in the count: more voxels than one slab of the volume's frustum share alone could give
     assert leg["integrate_voxels_per_launch_all_ranks"] > 0 and leg["integrate_ms_slowest_rank"] > 0
+    assert leg["integrate_voxels_per_s_all_ranks"] > 0
+    # both exchanges were timed on a few frames and the faster one ran the leg
+    probe = leg["exchange_probe_ms_per_frame"]
+    assert set(probe) == {"gather", "tiles"} and all(v > 0 for v in probe.values())
+    assert leg["exchange"].startswith("all-gather" if probe["gather"] <= probe["tiles"] else "all-to-all")
