@@ -81,6 +81,8 @@ def parse_args():
                          "sequence whose 2048^3 volume is sharded over the ranks), reported under zslab_<volume>")
     ap.add_argument("--zslab-steps", type=int, default=100, help="timed frames of the additional z-slab leg")
     ap.add_argument("--no-zslab-leg", action="store_true", help="N>1, replicas: skip the additional z-slab leg")
+    ap.add_argument("--no-icp-probe", action="store_true",
+                    help="z-slab leg: do not run the extra frames with the other ICP mode (replicated <-> all-reduced sums)")
     ap.add_argument("--zslab-timeout", type=float, default=240.0,
                     help="seconds after which rank 0 prints the line without a z-slab result and exits with status 4 "
                          "(below --pg-timeout, which aborts the process)")
@@ -352,6 +354,25 @@ def zslab_leg(a, rank, world, dist, torch, backend, V, steps, solo=False):
     ate_rmse = ate(est, gt[:n_fwd], ts[:n_fwd], ts[:n_fwd])["rmse"]
     elapsed, t_int, neg_tracked = reduce_ranks([elapsed, t_int, -tracked], "max", dist, torch, backend, world)
     (voxels,) = reduce_ranks([(boxes1 - boxes0) * voxels_per_box], "sum", dist, torch, backend, world)
+    # the same stream a little further with the other ICP mode: the configuration names all-reduced sums, the default
+    # replicates the tracking (no collective in the iteration chain)
+    other = None
+    if world > 1 and not a.no_icp_probe:
+        other_mode = "allreduce" if sharded.icp == "replicated" else "replicated"
+        sharded.icp = other_mode
+        at, n_other = total, 40
+        for i in range(8):
+            sharded.process_frame(ptrs[order[at + i]])
+        kf.sync()
+        dist.barrier()
+        tp = time.perf_counter()
+        for i in range(8, 8 + n_other):
+            sharded.process_frame(ptrs[order[at + i]])
+        kf.sync()
+        (t_other,) = reduce_ranks([time.perf_counter() - tp], "max", dist, torch, backend, world)
+        ok = sum(int(kf.status(kf.frame - 1 - k)["tracked"]) for k in range(n_other))
+        other = {"icp": other_mode, "frames_per_s": n_other / t_other, "ms_per_step": t_other / n_other * 1e3,
+                 "steps": n_other, "tracked_fraction": ok / n_other}
     sharded.close()
     del d_depth
     vox_per_launch = voxels / n_int if n_int else None
@@ -371,6 +392,7 @@ def zslab_leg(a, rank, world, dist, torch, backend, V, steps, solo=False):
         "integrate_voxels_per_s_all_ranks": vox_per_launch / t_int if (n_int and t_int > 0) else None,
         "tracked_fraction": -neg_tracked / max(1, steps),
         "ate_rmse_m": ate_rmse,
+        "other_icp_mode": other,
         "roofline": {"kernel": "k_integrate_plan + k_integrate", "bound": "hbm", "achieved": achieved,
                      "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
                      "frac": achieved / (HBM_PEAK_GBS * world) if achieved else None, "traffic": None,

@@ -166,6 +166,9 @@ def test_bench_with_two_ranks_reports_the_replica_leg_and_the_zslab_leg(torch_cu
     # both ranks' boxes are in the count: more voxels than one slab of the volume's frustum share alone could give
     assert leg["integrate_voxels_per_launch_all_ranks"] > 0 and leg["integrate_ms_slowest_rank"] > 0
     assert leg["integrate_voxels_per_s_all_ranks"] > 0
+    # a few more frames with the ICP sums all-reduced (what the configuration names; replicated tracking is the default)
+    other = leg["other_icp_mode"]
+    assert other["icp"] == "allreduce" and other["frames_per_s"] > 0 and other["tracked_fraction"] == 1.0
     # both exchanges were timed on a few frames and the faster one ran the leg
     probe = leg["exchange_probe_ms_per_frame"]
     assert set(probe) == {"gather", "tiles"} and all(v > 0 for v in probe.values())
