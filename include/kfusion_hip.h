@@ -223,6 +223,10 @@ int kfh_track_rows(kfh_context *ctx, int share, int share_count, kfh_allreduce_f
  * is copied and no collective library is involved.  The devices order themselves by events; the calling thread only
  * queues.  Results are those of kfh_raycast_slab + an all-gather + kfh_composite_slabs, bit for bit.
  * A group of one member is a plain context.  At most 16 members; calls on one group must not overlap.
+ * Up to three members every member composites the whole image (it reads the other members' whole segment maps); from
+ * four members on the image is split: a member selects the nearest hit for its 1/N of the pixels and stores the result
+ * into every member's map (two maps' worth of bytes over the links per member, whatever N).  KFH_GROUP_EXCHANGE=gather /
+ * share in the environment at creation decides otherwise.
  * When the members sit on more than one device, kfh_group_process_frame queues each member's launches from a host
  * thread of that member (created with the group, joined twice per frame); KFH_GROUP_THREADS=0 / 1 in the
  * environment at creation decides otherwise. */

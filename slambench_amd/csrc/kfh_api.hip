@@ -4,6 +4,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -1341,6 +1342,9 @@ struct kfh_group {
     std::vector<kfh_context *> member;
     std::vector<float4 *> segments;          // per member: the packed map its slab march writes (on its device)
     std::vector<hipEvent_t> marched, composited;
+    std::vector<float4 *> maps;              // per member: its packed model map (what its tracking reads)
+    std::vector<hipEvent_t> shared;          // per member: its share of the image is in every member's map
+    bool by_share = false;                   // the image is split among the members (from four members on)
     bool exchanged = false;                  // a composite has been queued since the group was created or reset
     GroupWorkers *workers = nullptr;         // null: the calling thread queues every member's launches itself
 };
@@ -1367,6 +1371,7 @@ void group_free(kfh_group *g) {
         if (i < g->segments.size() && g->segments[i]) (void)hipFree(g->segments[i]);
         if (i < g->marched.size() && g->marched[i]) (void)hipEventDestroy(g->marched[i]);
         if (i < g->composited.size() && g->composited[i]) (void)hipEventDestroy(g->composited[i]);
+        if (i < g->shared.size() && g->shared[i]) (void)hipEventDestroy(g->shared[i]);
     }
     for (kfh_context *c : g->member)
         if (c) (void)kfh_destroy(c);
@@ -1394,6 +1399,16 @@ int kfh_group_create(const kfh_config *cfg, const int *devices, int n, kfh_group
     g->segments.assign(n, nullptr);
     g->marched.assign(n, nullptr);
     g->composited.assign(n, nullptr);
+    g->shared.assign(n, nullptr);
+    g->maps.assign(n, nullptr);
+    // Every member compositing the whole image reads N - 1 whole segment maps from its peers; with the image split
+    // among the members it reads N - 1 shares and writes its own share N - 1 times (two maps' worth in all), at the
+    // price of a second round of events.  KFH_GROUP_EXCHANGE=gather / share decides otherwise.
+    g->by_share = n >= 4;
+    if (const char *e = std::getenv("KFH_GROUP_EXCHANGE")) {
+        if (std::strcmp(e, "share") == 0) g->by_share = n > 1;
+        else if (std::strcmp(e, "gather") == 0) g->by_share = false;
+    }
     int rc = KFH_OK;
     for (int i = 0; i < n && rc == KFH_OK; ++i) {
         // every member reads every other member's segment map: the devices must see each other's memory
@@ -1421,6 +1436,8 @@ int kfh_group_create(const kfh_config *cfg, const int *devices, int n, kfh_group
         hipError_t e = dev_alloc(&g->segments[i], (size_t)c->w * c->h);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&g->marched[i], hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&g->composited[i], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&g->shared[i], hipEventDisableTiming);
+        g->maps[i] = c->d_ref_tn;
         if (e != hipSuccess) rc = fail(KFH_ERR_HIP, "group member %d: %s", i, hipGetErrorString(e));
     }
     (void)hipSetDevice(caller_device);
@@ -1500,14 +1517,23 @@ int group_member_first_half(kfh_group *g, int i, bool raycasts) {
     if (int rc = kfh_track(c)) return rc;
     if (int rc = kfh_integrate(c)) return rc;
     if (raycasts) {
-        // the march overwrites the map the peers composited from in the frame before
-        if (g->exchanged)
+        // the march overwrites the map the peers composited from in the frame before (with the image split among the
+        // members this member has already waited for their shares, which they wrote after reading its map)
+        if (g->exchanged && !g->by_share)
             for (int j = 0; j < n; ++j)
                 if (j != i) KFH_HIP(hipStreamWaitEvent(c->stream, g->composited[j], 0));
         if (int rc = raycast_slab_to(c, g->segments[i])) return rc;
         KFH_HIP(hipEventRecord(g->marched[i], c->stream));
     }
     return KFH_OK;
+}
+
+// pixels [first, first + count) of the image are member i's share
+void group_share(const kfh_group *g, int i, int *first, int *count) {
+    const int n = (int)g->member.size(), npix = g->member[0]->w * g->member[0]->h;
+    const int share = ((npix + n - 1) / n + 63) / 64 * 64;
+    *first = std::min(i * share, npix);
+    *count = std::min(share, npix - *first);
 }
 
 // What member i queues once every member's `marched` event of this frame has been recorded on the host side.
@@ -1519,9 +1545,26 @@ int group_member_second_half(kfh_group *g, int i, bool raycasts) {
         for (int j = 0; j < n; ++j)
             if (j != i) KFH_HIP(hipStreamWaitEvent(c->stream, g->marched[j], 0));
         c->model_maps_stale = true;
+        if (g->by_share) {
+            int first = 0, count = 0;
+            group_share(g, i, &first, &count);
+            KFH_HIP(launch_composite_share(g->maps.data(), g->segments.data(), n, first, count, c->stream));
+            KFH_HIP(hipEventRecord(g->shared[i], c->stream));
+            return KFH_OK;                  // the frame ends in the third round, behind the peers' shares
+        }
         KFH_HIP(launch_composite_parts(c->d_ref_tn, g->segments.data(), n, c->w * c->h, c->stream));
         KFH_HIP(hipEventRecord(g->composited[i], c->stream));
     }
+    return kfh_end_frame(c);
+}
+
+// Split image only: member i's map is complete when every peer has stored its share into it.
+int group_member_third_half(kfh_group *g, int i) {
+    const int n = (int)g->member.size();
+    kfh_context *c = g->member[i];
+    DeviceScope on_device(c->device);
+    for (int j = 0; j < n; ++j)
+        if (j != i) KFH_HIP(hipStreamWaitEvent(c->stream, g->shared[j], 0));
     return kfh_end_frame(c);
 }
 }  // namespace
@@ -1533,14 +1576,20 @@ int kfh_group_process_frame(kfh_group *g) {
     const bool raycasts = g->member[0]->frame > 2;
     // Two rounds with a host-side join between them: a stream can only be told to wait for an event that has been
     // recorded already, so every member's march must be queued before any member queues its composite.
+    const bool third = raycasts && g->by_share;
     if (g->workers) {
         if (int rc = g->workers->run([g, raycasts](int i) { return group_member_first_half(g, i, raycasts); })) return rc;
         if (int rc = g->workers->run([g, raycasts](int i) { return group_member_second_half(g, i, raycasts); })) return rc;
+        if (third)
+            if (int rc = g->workers->run([g](int i) { return group_member_third_half(g, i); })) return rc;
     } else {
         for (int i = 0; i < n; ++i)
             if (int rc = group_member_first_half(g, i, raycasts)) return rc;
         for (int i = 0; i < n; ++i)
             if (int rc = group_member_second_half(g, i, raycasts)) return rc;
+        if (third)
+            for (int i = 0; i < n; ++i)
+                if (int rc = group_member_third_half(g, i)) return rc;
     }
     if (raycasts) g->exchanged = true;
     return KFH_OK;

@@ -229,6 +229,8 @@ hipError_t launch_composite(float4 *ref_tn, const float4 *tn_parts, int n_parts_
 // the same with one pointer per slab (own or peer memory); at most KFH_GROUP_MAX slabs
 constexpr int KFH_GROUP_MAX = 16;
 hipError_t launch_composite_parts(float4 *ref_tn, const float4 *const *parts, int n, int npix, hipStream_t s);
+hipError_t launch_composite_share(float4 *const *outs, const float4 *const *parts, int n, int first, int count,
+                                  hipStream_t s);
 // diagnostics: per-wavefront records of every following raycast launch go to d_buffer (null: off)
 void set_raycast_debug(unsigned long long *d_buffer);
 void set_integrate_debug(unsigned long long *d_buffer);

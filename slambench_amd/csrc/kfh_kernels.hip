@@ -3195,6 +3195,44 @@ hipError_t launch_composite_parts(float4 *ref_tn, const float4 *const *parts, in
     return hipGetLastError();
 }
 
+// The same selection for the pixels [first, first + count) only, the result stored into EVERY member's map: with the
+// image split among the members each one reads N candidates for 1/N of the pixels and writes its share N times, so a
+// member moves about two maps' worth of bytes over the links however many members there are (k_composite_parts reads
+// N - 1 whole maps from its peers).
+struct CompositeOuts { float4 *out[KFH_GROUP_MAX]; };
+__global__ __launch_bounds__(256) void k_composite_share(CompositeOuts outs, CompositeParts parts, int n, int first,
+                                                         int count) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= count) return;
+    const int p = first + q;
+    float4 cand[KFH_GROUP_MAX];
+#pragma unroll
+    for (int i = 0; i < KFH_GROUP_MAX; ++i)
+        cand[i] = i < n ? parts.part[i][p] : make_float4(0.f, KFH_INVALID, 0.f, 0.f);
+    float4 best = make_float4(0.f, KFH_INVALID, 0.f, 0.f);
+    bool have = false;
+#pragma unroll
+    for (int i = 0; i < KFH_GROUP_MAX; ++i)
+        if (i < n && cand[i].x > 0.f && (!have || cand[i].x < best.x)) { best = cand[i]; have = true; }
+#pragma unroll
+    for (int i = 0; i < KFH_GROUP_MAX; ++i)
+        if (i < n) outs.out[i][p] = best;
+}
+
+hipError_t launch_composite_share(float4 *const *outs, const float4 *const *parts, int n, int first, int count,
+                                  hipStream_t s) {
+    if (n < 1 || n > KFH_GROUP_MAX || first < 0 || count < 0) return hipErrorInvalidValue;
+    if (count == 0) return hipSuccess;
+    CompositeParts cp;
+    CompositeOuts co;
+    for (int i = 0; i < KFH_GROUP_MAX; ++i) {
+        cp.part[i] = i < n ? parts[i] : nullptr;
+        co.out[i] = i < n ? outs[i] : nullptr;
+    }
+    hipLaunchKernelGGL(k_composite_share, dim3((count + 255) / 256), dim3(256), 0, s, co, cp, n, first, count);
+    return hipGetLastError();
+}
+
 // Vertex, normal and hit-distance maps of the last raycast rebuilt from the packed map {t, normal}: the raycast
 // stored vertex = origin + direction * t with direction = rotate(view, (x, y, 1)); the same expressions on the same
 // matrix give the same bits, so a caller sees exactly what the raycast would have written.

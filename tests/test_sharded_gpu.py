@@ -158,10 +158,14 @@ def test_slab_raycast_with_brick_marks_equals_the_one_without(torch_cuda, monkey
     assert (maps[-1][..., 0] > 0).any(axis=0).mean() > 0.5          # the composite hits most pixels
 
 
-@pytest.mark.parametrize("members,threads", [(2, "0"), (3, "0"), (3, "1"), (5, "1")])
-def test_group_inside_one_process_gives_the_bits_of_the_gather_exchange(torch_cuda, monkeypatch, members, threads):
-    """kfh_group (the members' composites reading each other's segment maps in place, ordered by events; launches
-    queued by the calling thread or, as for members on several devices, by one host thread per member)
+@pytest.mark.parametrize("members,threads,exchange", [(2, "0", "gather"), (3, "0", "gather"), (3, "1", "gather"),
+                                                      (5, "1", "share"), (2, "0", "share"), (3, "1", "share"),
+                                                      (4, "0", "")])
+def test_group_inside_one_process_gives_the_bits_of_the_gather_exchange(torch_cuda, monkeypatch, members, threads,
+                                                                        exchange):
+    """kfh_group (the members' composites reading each other's segment maps in place, ordered by events - every member
+    the whole image, or each its share of the pixels stored into every member's map; launches queued by the calling
+    thread or, as for members on several devices, by one host thread per member)
     against the construction above: every slab marched by kfh_raycast_slab, the segment maps stacked and every context
     compositing with kfh_composite_slabs - what the one-process-per-rank path does with an all-gather in between."""
     from slambench_amd.kfusion import GroupKFusion
@@ -184,7 +188,11 @@ def test_group_inside_one_process_gives_the_bits_of_the_gather_exchange(torch_cu
                 native.check(L.kfh_composite_slabs(kf._ctx, C.c_void_p(tn.data_ptr()), members))
         for kf in slabs:
             kf.end_frame()
-    monkeypatch.setenv("KFH_GROUP_THREADS", threads)           # read when the group is created
+    monkeypatch.setenv("KFH_GROUP_THREADS", threads)           # both read when the group is created
+    if exchange:                                               # "": the default (the image split from four members on)
+        monkeypatch.setenv("KFH_GROUP_EXCHANGE", exchange)
+    else:
+        monkeypatch.delenv("KFH_GROUP_EXCHANGE", raising=False)
     group = GroupKFusion(KFusionConfig(**base), [0] * members)
     for i in range(frames):
         group.process_frame(depth[i])
