@@ -81,6 +81,9 @@ def parse_args():
                          "sequence whose 2048^3 volume is sharded over the ranks), reported under zslab_<volume>")
     ap.add_argument("--zslab-steps", type=int, default=100, help="timed frames of the additional z-slab leg")
     ap.add_argument("--no-zslab-leg", action="store_true", help="N>1, replicas: skip the additional z-slab leg")
+    ap.add_argument("--no-group-leg", action="store_true",
+                    help="N>1, replicas: skip the leg that runs the same z-slab configuration through the in-process "
+                         "group (kfh_group) on rank 0")
     ap.add_argument("--no-icp-probe", action="store_true",
                     help="z-slab leg: do not run the extra frames with the other ICP mode (replicated <-> all-reduced sums)")
     ap.add_argument("--zslab-timeout", type=float, default=240.0,
@@ -421,6 +424,57 @@ def zslab_leg(a, rank, world, dist, torch, backend, V, steps, solo=False):
     }
 
 
+def group_leg(a, world, n_devices, torch, V, steps):
+    """The same configuration through the library's in-process group (kfh_group_*: what the plugin's --devices N
+    uses, the harness being one process): `world` z-slab contexts on the devices 0..world-1 of THIS process (wrapping
+    round when there are fewer devices), the members reading each other's ray segments in place over peer access.
+    Rank 0 runs it while the other ranks wait."""
+    from slambench_amd import synth
+    from slambench_amd.config import KFusionConfig, TUM_FR1_DEPTH_INTRINSICS
+    from slambench_amd.kfusion import GroupKFusion
+    from slambench_amd.metrics import ate
+
+    cfg = KFusionConfig(input_size=(640, 480), intrinsics=TUM_FR1_DEPTH_INTRINSICS, volume_resolution=(V, V, V))
+    untimed = 8
+    total = steps + untimed
+    n_unique = max(8, min(40, total))
+    depth, gt, ts = synth.make_sequence(n_unique, seed=1, intrinsics=TUM_FR1_DEPTH_INTRINSICS, noise=True)
+    order = ping_pong(n_unique, total)
+    devices = [m % n_devices for m in range(world)]
+    home = torch.cuda.current_device()
+    resident = {}                        # per device: the stream's frames in that device's memory
+    for d in sorted(set(devices)):
+        with torch.cuda.device(d):
+            resident[d] = torch.from_numpy(depth.view(np.int16)).cuda()
+    ptrs = [[int(resident[d][i].data_ptr()) for d in devices] for i in range(n_unique)]
+    group = GroupKFusion(cfg, devices)
+    try:
+        for i in range(untimed):
+            group.process_frame(ptrs[order[i]])
+        group.sync()
+        t0 = time.perf_counter()
+        for i in range(untimed, total):
+            group.process_frame(ptrs[order[i]])
+        group.sync()
+        elapsed = time.perf_counter() - t0
+        first = group.members[0]
+        tracked = sum(int(first.status(f)["tracked"]) for f in range(untimed, total))
+        n_fwd = min(total, n_unique)
+        est = np.stack([first.status(f)["pose"] for f in range(n_fwd)])
+        ate_rmse = ate(est, gt[:n_fwd], ts[:n_fwd], ts[:n_fwd])["rmse"]
+    finally:
+        group.close()
+        torch.cuda.set_device(home)
+    return {
+        "workload": "ONE synthetic 640x480 sequence, %d^3 TSDF over 8 m in %d z-slabs inside one process (kfh_group), "
+                    "ICP replicated" % (V, world),
+        "members": world, "devices": sorted(set(devices)),
+        "exchange": os.environ.get("KFH_GROUP_EXCHANGE") or ("share" if world >= 4 else "gather"),
+        "steps": steps, "frames_per_s": steps / elapsed, "ms_per_step": elapsed / steps * 1e3,
+        "tracked_fraction": tracked / max(1, steps), "ate_rmse_m": ate_rmse,
+    }
+
+
 def main():
     a = parse_args()
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -758,7 +812,8 @@ def main():
             import threading
 
             def give_up():
-                result["zslab_%d" % a.zslab_volume] = {"error": "no result within %d s" % a.zslab_timeout}
+                result.setdefault("zslab_%d" % a.zslab_volume, {"error": "no result within %d s" % a.zslab_timeout})
+                result.setdefault("zslab_%d_in_process" % a.zslab_volume, {"error": "no result within %d s" % a.zslab_timeout})
                 print(json.dumps(result))
                 sys.stdout.flush()
                 os._exit(4)
@@ -772,10 +827,22 @@ def main():
             leg_failed = True
             leg = {"error": "%s: %s" % (type(exc).__name__, exc)}
             sys.stderr.write("bench.py: rank %d: z-slab leg failed: %s\n" % (rank, leg["error"]))
-        if watchdog is not None:
-            watchdog.cancel()
         if rank == 0:
             result["zslab_%d" % a.zslab_volume] = leg
+        if not leg_failed and not a.no_group_leg:
+            # the in-process group on the same devices, by rank 0 alone (the others have freed theirs and wait)
+            torch.cuda.empty_cache()
+            dist.barrier()
+            if rank == 0:
+                try:
+                    result["zslab_%d_in_process" % a.zslab_volume] = group_leg(a, world, n_devices, torch, a.zslab_volume,
+                                                                             a.zslab_steps)
+                except Exception as exc:                # reported, but the run's other results stand
+                    result["zslab_%d_in_process" % a.zslab_volume] = {"error": "%s: %s" % (type(exc).__name__, exc)}
+                    sys.stderr.write("bench.py: in-process group leg failed: %s\n" % exc)
+            dist.barrier()
+        if watchdog is not None:
+            watchdog.cancel()
     if world > 1 or solo_exchange:
         if not leg_failed:
             dist.barrier()

@@ -166,6 +166,11 @@ def test_bench_with_two_ranks_reports_the_replica_leg_and_the_zslab_leg(torch_cu
     # both ranks' boxes are in the count: more voxels than one slab of the volume's frustum share alone could give
     assert leg["integrate_voxels_per_launch_all_ranks"] > 0 and leg["integrate_ms_slowest_rank"] > 0
     assert leg["integrate_voxels_per_s_all_ranks"] > 0
+    # the same configuration through the in-process group, run by rank 0 on the same device(s)
+    grp = d["zslab_256_in_process"]
+    assert "error" not in grp, grp
+    assert grp["members"] == 2 and grp["frames_per_s"] > 0 and grp["tracked_fraction"] == 1.0
+    assert abs(grp["ate_rmse_m"] - leg["ate_rmse_m"]) < 1e-3
     # a few more frames with the ICP sums all-reduced (what the configuration names; replicated tracking is the default)
     other = leg["other_icp_mode"]
     assert other["icp"] == "allreduce" and other["frames_per_s"] > 0 and other["tracked_fraction"] == 1.0
