@@ -241,7 +241,9 @@ int kfh_group_member(kfh_group *group, int index, kfh_context **ctx);
 int kfh_group_upload_depth(kfh_group *group, const uint16_t *h_depth);      /* the same host frame to every member */
 /* d_depth_per_member[i]: the frame in the memory of member i's device */
 int kfh_group_set_depth_device(kfh_group *group, const uint16_t *const *d_depth_per_member);
-int kfh_group_process_frame(kfh_group *group);   /* Kfusion's four stages + the exchange, queued on every member */
+/* Kfusion's four stages + the exchange, queued on every member.  When it returns an error some members may have queued
+ * more of the frame than others: the group must be reset (kfh_group_reset) or destroyed before it is used again. */
+int kfh_group_process_frame(kfh_group *group);
 int kfh_group_sync(kfh_group *group);
 int kfh_group_get_pose(kfh_group *group, float pose[16]);                   /* waits for every member */
 
