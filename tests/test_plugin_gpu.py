@@ -220,10 +220,14 @@ def test_reference_written_files_and_reference_frame_counting(torch_cuda, tmp_pa
     np.testing.assert_allclose(harness.parse_log(r.stdout)[2][:, 1], ts[2:5], atol=1e-8)
 
 
-def test_devices_option_splits_the_volume_inside_the_plugin(torch_cuda, tmp_path):
+@pytest.mark.parametrize("group_env", [{}, {"KFH_GROUP_THREADS": "1", "KFH_GROUP_EXCHANGE": "share"}])
+def test_devices_option_splits_the_volume_inside_the_plugin(torch_cuda, tmp_path, monkeypatch, group_env):
     """`--devices 2`: the plugin runs the sequence on a group of two z-slab contexts (both on GPU 0 here) and the
     harness, a single process calling frame by frame, sees one library: its trajectory is the one of the in-process
-    two-slab construction of tests/test_sharded_gpu.py (kfh_raycast_slab + stacked maps + kfh_composite_slabs)."""
+    two-slab construction of tests/test_sharded_gpu.py (kfh_raycast_slab + stacked maps + kfh_composite_slabs) - also
+    with a host thread per member and the image split between the members, as a group on several devices runs."""
+    for k, v in group_env.items():
+        monkeypatch.setenv(k, v)              # the harness process inherits them
     import ctypes as C
     from slambench_amd import native
     from slambench_amd.sharded import slab_bounds
