@@ -5,6 +5,8 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -1286,10 +1288,21 @@ struct GroupWorkers {
     std::function<int(int)> job;
     std::vector<int> result;
     std::vector<std::string> text;
-    unsigned generation = 0;
-    int pending = 0;
-    bool stop = false;
+    std::atomic<unsigned> generation{0};
+    std::atomic<int> pending{0};
+    std::atomic<bool> stop{false};
+    // The rounds of a frame follow each other within microseconds, and waking a sleeping thread costs more than a
+    // round's launches: both sides poll for this long before they go to sleep on the condition variable.
+    static constexpr std::chrono::microseconds SPIN{200};
 
+    static bool spin_until(const std::function<bool()> &done_now) {
+        const auto t0 = std::chrono::steady_clock::now();
+        while (!done_now()) {
+            if (std::chrono::steady_clock::now() - t0 > SPIN) return false;
+            __builtin_ia32_pause();
+        }
+        return true;
+    }
     void start(int n, const std::vector<int> &device) {
         result.assign(n, 0);
         text.assign(n, std::string());
@@ -1300,11 +1313,12 @@ struct GroupWorkers {
         unsigned seen = 0;
         for (;;) {
             std::function<int(int)> mine;
+            spin_until([&] { return stop.load(std::memory_order_acquire) || generation.load(std::memory_order_acquire) != seen; });
             {
                 std::unique_lock<std::mutex> hold(lock);
-                go.wait(hold, [&] { return stop || generation != seen; });
-                if (stop) return;
-                seen = generation;
+                go.wait(hold, [&] { return stop.load() || generation.load() != seen; });
+                if (stop.load()) return;
+                seen = generation.load();
                 mine = job;
             }
             const int rc = mine(i);
@@ -1312,16 +1326,22 @@ struct GroupWorkers {
             std::lock_guard<std::mutex> hold(lock);
             result[i] = rc;
             text[i].swap(why);
-            if (--pending == 0) done.notify_one();
+            if (pending.fetch_sub(1, std::memory_order_acq_rel) == 1) done.notify_one();
         }
     }
     int run(const std::function<int(int)> &f) {
-        std::unique_lock<std::mutex> hold(lock);
-        job = f;
-        pending = (int)threads.size();
-        ++generation;
+        {
+            std::lock_guard<std::mutex> hold(lock);
+            job = f;
+            pending.store((int)threads.size(), std::memory_order_release);
+            generation.fetch_add(1, std::memory_order_acq_rel);
+        }
         go.notify_all();
-        done.wait(hold, [&] { return pending == 0; });
+        if (!spin_until([&] { return pending.load(std::memory_order_acquire) == 0; })) {
+            std::unique_lock<std::mutex> hold(lock);
+            done.wait(hold, [&] { return pending.load() == 0; });
+        }
+        std::lock_guard<std::mutex> hold(lock);            // the last worker has left its critical section
         for (size_t i = 0; i < result.size(); ++i)
             if (result[i] != KFH_OK) return fail(result[i], "group member %zu: %s", i, text[i].c_str());
         return KFH_OK;
@@ -1329,13 +1349,14 @@ struct GroupWorkers {
     void finish() {
         {
             std::lock_guard<std::mutex> hold(lock);
-            stop = true;
+            stop.store(true);
         }
         go.notify_all();
         for (std::thread &t : threads) t.join();
         threads.clear();
     }
 };
+constexpr std::chrono::microseconds GroupWorkers::SPIN;
 }  // namespace
 
 struct kfh_group {
