@@ -58,7 +58,9 @@ def _draw(seed):
     scale = float(rng.choice([1000.0, 1500.0, 700.0]))  # depth units per metre: surfaces between 0.5 and 4 m
     z0 = int(rng.integers(0, res[2] - 1))
     z1 = int(rng.integers(z0 + 1, res[2] + 1))
-    return dict(w=w, h=h, res=res, dim=dim, poses=poses, k=k, mu=mu, scale=scale, slab=(z0, z1), seed=seed)
+    maxweight = float(rng.choice([100.0, 100.0, 2.0, 1.0, 2.5]))      # (drawn last: the cases above stay what they were)
+    return dict(w=w, h=h, res=res, dim=dim, poses=poses, k=k, mu=mu, scale=scale, slab=(z0, z1), seed=seed,
+                maxweight=maxweight)
 
 
 @pytest.mark.parametrize("seed", range(int(os.environ.get("KFH_KERNEL_FUZZ_SEEDS", "12"))))
@@ -77,10 +79,10 @@ def test_integrate_and_raycast_random_case(torch_cuda, seed):
         inv_pose = kf_ref.mat_inverse(pose)
         if first is None:
             first = (depth, inv_pose)
-        kf_ref.integrate(vol_ref, dim, depth, inv_pose, K, mu, 100.0)
+        kf_ref.integrate(vol_ref, dim, depth, inv_pose, K, mu, c["maxweight"])
         d = torch.from_numpy(depth).cuda()
         native.check(L.kfh_k_integrate(vp(vol), res_c, dim_c, 0, res[2], vp(d), w, h, hp(m4(inv_pose)), hp(m4(K)),
-                                       mu, 100.0, None))
+                                       mu, c["maxweight"], None))
     assert np.array_equal(vol.cpu().numpy(), vol_ref), c
     _seen["cases"] += 1
     _seen["fused"] += int((vol_ref[..., 1] > 0).sum() > 500)

@@ -340,6 +340,36 @@ def test_integrate_bit_exact(torch_cuda, L, scene, res):
     assert np.array_equal(got, vol_ref)
 
 
+@pytest.mark.parametrize("maxweight", [1.0, 2.0, 2.5, 3.0])
+def test_integrate_with_saturating_weights(torch_cuda, L, scene, maxweight):
+    """Weights that reach the cap after one to three frames and stay there (a free-space voxel at the cap is no longer
+    stored at all, a voxel near the surface keeps averaging with the capped weight); a cap that is no integer is
+    truncated when the weight is stored, as the reference's conversion to short does."""
+    torch = torch_cuda
+    cfg = scene["cfg"]
+    w, h = cfg.compute_size
+    K = kf_ref.camera_matrix(cfg.camera)
+    for res, dim in (((128, 64, 96), (8.0, 8.0, 8.0)), ((96, 96, 96), (1.5, 1.5, 1.5))):
+        # (the small volume lies wholly inside the image in front of the surfaces: whole columns of free space, which
+        # take the march with two columns per lane)
+        vol_ref = kf_ref.new_volume(res)
+        vol = torch.from_numpy(vol_ref.copy()).cuda()
+        res_c, dim_c = (C.c_int32 * 3)(*res), (C.c_float * 3)(*dim)
+        for i in range(6):
+            depth = kf_ref.mm2meters(scene["depth"][i % 3], w, h, 1000.0)
+            pose = scene["gt"][i % 3].astype(np.float32)
+            if dim[0] < 8.0:                   # the small volume starts 0.4 m in front of the camera, centred on its axis
+                pose = pose.copy()
+                pose[:3, 3] = pose[:3, :3] @ np.array([0.75, 0.75, -0.4], np.float32)
+            inv_pose = kf_ref.mat_inverse(pose)
+            kf_ref.integrate(vol_ref, dim, depth, inv_pose, K, 0.1, maxweight)
+            d = torch.from_numpy(depth).cuda()
+            native.check(L.kfh_k_integrate(vp(vol), res_c, dim_c, 0, res[2], vp(d), w, h, hp(m4(inv_pose)), hp(m4(K)),
+                                           0.1, maxweight, None))
+            assert np.array_equal(vol.cpu().numpy(), vol_ref), (res, i)
+        assert int(vol_ref[..., 1].max()) == int(maxweight) and (vol_ref[..., 1] == int(maxweight)).sum() > 1000
+
+
 def test_integrate_slab_equals_full(torch_cuda, L, scene):
     """A z-slab [z0, z1) whose storage starts at plane z0 gets exactly the voxels of the full volume."""
     torch = torch_cuda
